@@ -1,0 +1,186 @@
+/* vdn.h — C-ABI of libvdn_hip.so: the MI355X (gfx950) kernels behind
+ * DepthAnythingV2.forward / VideoDepthAnything.forward.
+ *
+ * The reference has no FFI for this path: callers hold a torch.nn.Module and every op below is a
+ * torch.nn.functional call inside it. Each entry point therefore names the
+ * reference call site(s) it replaces (paths relative to the reference root). The Python host
+ * mirror (video-depth-normal-v2_amd/vdn) binds these with ctypes; INTEGRATION.md shows the stub
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every buffer is caller-owned device memory (hipMalloc'd by
+ *    PyTorch-ROCm), the library allocates nothing and keeps no state;
+ *  - every launch is asynchronous on `stream` (torch.cuda.current_stream().cuda_stream);
+ *  - return 0 on success, a negative vdn_status on a rejected argument, or -(1000+hipError_t);
+ *  - "half" = the 16-bit MFMA operand type chosen per call by `dt`: VDN_F16 (IEEE fp16, default:
+ *    same MFMA rate as bf16 with 8x smaller rounding, and what the reference's own video driver
+ *    autocasts to, video_depth_anything/video_depth.py:106) or VDN_BF16;
+ *  - activations are channels-last: tokens [B, N, C] == NHWC feature maps [B, H, W, C].
+ */
+#ifndef VDN_H
+#define VDN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vdn_stream; /* hipStream_t */
+
+enum vdn_status { VDN_OK = 0, VDN_EINVAL = -1, VDN_EUNSUPPORTED = -2, VDN_EALIGN = -3 };
+enum vdn_dtype { VDN_F16 = 0, VDN_BF16 = 1, VDN_F32 = 2, VDN_NONE = 3 };
+enum vdn_act { VDN_ACT_NONE = 0, VDN_ACT_GELU = 1, VDN_ACT_RELU = 2 };
+enum vdn_amode { VDN_A_PLAIN = 0, VDN_A_CONV3X3 = 1 };
+enum vdn_store {
+  VDN_ST_PLAIN = 0,   /* out[row(m) * ldc + n]                                                   */
+  VDN_ST_HEADS = 1,   /* n -> (split, head, e<64); per-split buffer, token- or dim-major          */
+  VDN_ST_CONVT = 2,   /* ConvTranspose2d with kernel == stride: pixel-shuffle scatter to NHWC      */
+  VDN_ST_GEGLU = 3    /* weight rows packed as 16-row blocks [h | gate]; out = h * gelu(gate)      */
+};
+
+/* One descriptor drives every GEMM-shaped op on the path:
+ *   out = epilogue( A[M,K] x W[N,K]^T ),  half operands, fp32 accumulate on MFMA.
+ * Replaces F.linear / nn.Conv2d(1x1, 3x3 s1|s2 p1) / nn.ConvTranspose2d(k==s) at:
+ *   depth_anything_v2/dinov2_layers/attention.py:51,60 (qkv, proj), mlp.py:36,39 (fc1, fc2),
+ *   patch_embed.py:76 (14x14 s14 conv == GEMM on patchified rows),
+ *   depth_anything_v2/dpt.py:129-130 (projects, resize_layers), util/blocks.py:68-74 (RCU convs),
+ *   :146 (out_conv), dpt.py:135-138 (layerN_rn), :145,148 (output_conv1/2),
+ *   video_depth_anything/motion_module/motion_module.py:116,131 (proj_in/out), :273,280-281
+ *   (to_q/k/v), :315 (to_out), attention.py:383-384 (GEGLU), :329 (ff out),
+ *   sam2/modeling/sam/transformer.py:279-281,309 (q/k/v/out_proj), memory_attention.py:96
+ *   (linear1/2), memory_encoder.py:108-110 (pwconv1/2), :172 (pix_feat_proj).                   */
+typedef struct vdn_gemm_desc {
+  int32_t dt;            /* vdn_dtype of A and W (VDN_F16 | VDN_BF16)                             */
+  int32_t M, N, K;       /* K = logical reduction length (conv: 9*Cin), multiple of 8             */
+  /* A operand */
+  const void* A;         /* plain: half [M, lda]; conv: half NHWC [cB, cH, cW, cC]                */
+  int32_t a_mode;        /* vdn_amode                                                             */
+  int32_t lda;           /* elements                                                              */
+  int32_t relu_a;        /* apply ReLU to A on load (ResidualConvUnit's activation on its input)  */
+  int32_t cB, cH, cW, cC, cOH, cOW, cstride; /* conv geometry (pad 1), M == cB*cOH*cOW            */
+  /* W operand: half [N, ldb], K-contiguous, zero-padded to ldb (multiple of 64, >= K)            */
+  const void* W;
+  int32_t ldb;
+  /* epilogue, applied in fp32 in this order:
+   *   v = acc + bias[n] + rowadd[m];  v = act(v);  v *= gamma[n];
+   *   v += tab[(m % tab_mod + tab_off), n];  v += res1[m,n];  v += res2[m,n]                     */
+  const float* bias;     /* [N] or NULL                                                           */
+  const float* rowadd;   /* [M] or NULL                                                           */
+  int32_t act;           /* vdn_act                                                               */
+  const float* gamma;    /* [N] or NULL (LayerScale / CXBlock gamma)                              */
+  const float* tab;      /* f32 [*, N] or NULL (pos_embed)                                        */
+  int32_t tab_mod, tab_off;
+  const void* res1;      /* [M, ldr1] or NULL                                                     */
+  int32_t res1_dt, ldr1;
+  const void* res2;
+  int32_t res2_dt, ldr2;
+  /* store */
+  int32_t store;         /* vdn_store                                                             */
+  void* out;             /* PLAIN/CONVT/GEGLU destination                                         */
+  int32_t out_dt;        /* VDN_F16|VDN_BF16|VDN_F32                                              */
+  int32_t ldc;
+  int32_t row_group, row_skip; /* PLAIN: out row = m + (m / row_group + 1) * row_skip if row_group>0
+                                  (patch tokens land after each image's cls row)                 */
+  /* HEADS: N == nsplit * heads * 64. split s goes to dst[s]:
+   *   token-major  [Bt, heads, tpad, 64]  (transposed[s] == 0)
+   *   dim-major    [Bt, heads, 64, tpad]  (transposed[s] == 1, the V^T image the attention
+   *                                        kernel reads with contiguous keys)
+   * with m -> (bt = m / tokens, t = m % tokens + tok_off).
+   * rope[s] != 0 rotates adjacent pairs (2i,2i+1) of each head by rope_cs[(t % rope_mod), i]
+   * = (cos, sin) (sam2/modeling/position_encoding.py:212-239); requires the weight rows of that
+   * split to be packed pair-split (see vdn_pack.h / vdn/pack.py).                                */
+  void* dst[3];
+  int32_t nsplit, heads, tokens, tok_off, tpad;
+  int32_t transposed[3];
+  int32_t rope[3];
+  const float* rope_cs;  /* f32 [rope_mod, 32, 2]                                                 */
+  int32_t rope_mod;
+  /* CONVT: N == ck*ck*cout, n = (ky*ck + kx)*cout + co; m = (b, y, x) on a cB x cH x cW grid;
+   * out NHWC [cB, cH*ck, cW*ck, cout]                                                            */
+  int32_t ck, cout;
+  const void* zeros;     /* >= 16 bytes of zeros (conv padding taps / K tail read from here)      */
+} vdn_gemm_desc;
+
+int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
+
+/* LayerNorm over the last dim of [rows, C] (fp32 statistics, two-pass in registers).
+ *   y = LN(x) * w + b;  y += alpha * addvec[c];  y += addtab[(row / tab_div) % tab_mod, c]
+ * writes out_h (half, optional) and out_f (f32, optional).
+ * Replaces nn.LayerNorm at dinov2_layers/block.py:84,87 + dinov2.py:310 (eps 1e-6),
+ * memory_attention.py:60,74,93,162 (eps 1e-5), motion_module.py:179,189 (eps 1e-5, with the
+ * sinusoidal PE add of :211 fused as addtab), LayerNorm2d sam2_utils.py:148-153 on NHWC rows.    */
+int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
+                  const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
+                  void* out_h, int h_dt, float* out_f, vdn_stream stream);
+
+/* Fused attention forward, head_dim 64: out[b, q, h*64+e] = softmax(scale * Q K^T) V.
+ *   Q  half [BH, nq_pad, 64] (rows >= nq never read), K half [BH, nk_pad, 64],
+ *   Vt half [BH, 64, nk_pad] (dim-major; columns >= nk must be finite), nk_pad % 64 == 0.
+ * Scores never touch HBM. Replaces dinov2_layers/attention.py:53-59 and
+ * F.scaled_dot_product_attention at sam2/modeling/sam/transformer.py:306.                        */
+int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out,
+                   int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
+
+/* Temporal attention over <=32 frames per (pixel, head): qkv half [(b f), D, 3c] packed
+ * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)
+ * with the rearranges of motion_module.py:255,320.                                              */
+int vdn_temporal_attn(int dt, const void* qkv, void* out, int Bv, int T, int D, int c, int heads,
+                      float scale, vdn_stream stream);
+
+/* GroupNorm over NHWC half [F, HW, C] (fp32 stats per (frame, group)); `partial` is
+ * f32 [F, nsplit, groups, 2] scratch. Replaces motion_module.py:112 (32 groups, eps 1e-6).       */
+int vdn_groupnorm(int dt, const void* x, void* y, int F, int HW, int C, int groups, const float* w,
+                  const float* b, float eps, float* partial, int nsplit, vdn_stream stream);
+
+/* Bilinear resize, align_corners=True, NHWC half (C % 8 == 0) or single-channel f32.
+ * Replaces F.interpolate at util/blocks.py:144, dpt.py:147, depth_anything_v2.py:63,
+ * video_depth.py:63.                                                                             */
+int vdn_upsample_bilinear(int dt, const void* x, void* y, int B, int IH, int IW, int OH, int OW, int C,
+                          vdn_stream stream);
+int vdn_upsample_bilinear_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int relu,
+                              vdn_stream stream);
+
+/* f32 NCHW image [B,3,H,W] -> half rows [B*ph*pw, ldk] with k = (c*14+ky)*14+kx, zero tail.
+ * (the im2col-free view of PatchEmbed's 14x14 stride-14 conv, patch_embed.py:76)                 */
+int vdn_patchify(int dt, const float* img, void* rows, int B, int H, int W, int ldk, vdn_stream stream);
+
+/* x[b*rows_per_b + row, :] = vec[:] (cls_token + pos_embed[0], dinov2.py:219-220)                */
+int vdn_fill_row(float* x, const float* vec, int B, int rows_per_b, int row, int C, vdn_stream stream);
+
+/* Bicubic (A=-0.75, align_corners=False, scale-factor coordinate map) resample of the
+ * [gs,gs,C] pos_embed grid to [oh,ow,C] (dinov2.py:193-203).                                      */
+int vdn_bicubic_grid(const float* src, float* dst, int gs, int oh, int ow, int C, float sx, float sy,
+                     vdn_stream stream);
+
+/* y = x + alpha * vec[c]  (memory_attention.py:141)                                               */
+int vdn_add_vec(const float* x, const float* vec, float alpha, float* y, int rows, int C, vdn_stream stream);
+
+/* depth[m] = (relu?) (bias + sum_c w[c] * feat[m, c]), feat half [M, C<=64] already ReLU'd
+ * (the 1x1 conv + ReLU closing output_conv2, dpt.py:111-112)                                      */
+int vdn_head_out(int dt, const void* feat, const float* w, float bias, float* depth, int M, int C,
+                 int relu, vdn_stream stream);
+
+/* MaskDownSampler stages of memory_block.py:72-75 (sam2/modeling/memory_encoder.py:36-58):
+ * stage 1: sigmoid -> conv3x3 s2 p1 (1->4) -> LayerNorm2d -> GELU -> conv1x1 (4->1)
+ * stage 2:            conv7x7 s7    (1->49) -> LayerNorm2d -> GELU -> conv1x1 (49->1)
+ * w: packed f32 parameter block [conv w | conv b | ln w | ln b | proj w | proj b].                */
+int vdn_mask_down1(const float* depth, float* out, int B, int H, int W, int OH, int OW, const float* w,
+                   vdn_stream stream);
+int vdn_mask_down2(const float* in, float* out, int B, int H, int W, int OH, int OW, const float* w,
+                   vdn_stream stream);
+
+/* Depthwise 7x7 pad 3 conv on f32 NHWC [B,H,W,C], w f32 [49, C], bias [C] (CXBlock.dwconv,
+ * memory_encoder.py:101).                                                                         */
+int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const float* w, const float* bias,
+                vdn_stream stream);
+
+/* misc */
+int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);
+const char* vdn_version(void);
+int vdn_arch_ok(void); /* 1 if device 0 is gfx950 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the IMPORTED reference (read-only at /root/reference) on CPU.
+
+Runs only in the build container (the GPU box has no /root/reference). Three in-memory shims stand
+in for modules the reference imports but never needs on this path: cv2 (4 integer constants),
+torchvision.transforms.Compose, easydict.EasyDict. No reference source is copied: fixtures hold
+inputs' seeds and output numbers only.
+
+Usage: python tools/make_golden.py [--only NAME ...]
+Every fixture is also checked here against oracle/ref_cpu.py (max rel error printed, must be <=1e-5).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "video-depth-normal-v2_amd"))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+
+
+def install_shims():
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA = 0, 1, 2, 3
+    cv2.COLOR_BGR2RGB = 4
+    sys.modules["cv2"] = cv2
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tvt.Compose = Compose
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.__dict__ = self
+
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+    tq = types.ModuleType("tqdm")
+    tq.tqdm = lambda x, *a, **k: x
+    sys.modules.setdefault("tqdm", tq)
+    sys.path.insert(0, REF)
+
+
+def load_synth(model: torch.nn.Module):
+    from vdn import synth
+    sd = model.state_dict()
+    shapes = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
+    new = synth.synth_state_dict(shapes, SEED)
+    for k, v in new.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}, shapes
+
+
+def stats(t: torch.Tensor):
+    t = t.detach().float()
+    return np.array([t.mean().item(), t.std().item(), t.abs().max().item()], np.float64)
+
+
+def samples(t: torch.Tensor, n: int = 256):
+    """Fixed pseudo-random flat indices (depends only on numel) + values."""
+    flat = t.detach().float().reshape(-1)
+    idx = (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % flat.numel()
+    return idx, flat[torch.from_numpy(idx)].numpy()
+
+
+def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_inputs(n, h, w):
+    from vdn import synth
+    fr = synth.frames_u8(SEED, n, h, w)
+    return torch.from_numpy(synth.normalize_frames(fr))
+
+
+class PreRelu:
+    """Capture the input of the final nn.ReLU (= output of the 1x1 conv, pre-ReLU depth)."""
+
+    def __init__(self, conv):
+        self.val = []
+        self.h = conv.register_forward_hook(lambda m, i, o: self.val.append(o.detach().clone()))
+
+
+def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str):
+    from depth_anything_v2.depth_anything_v2 import DepthAnythingV2
+    from oracle import ref_cpu as O
+    cfg = O.MODEL_CONFIGS[enc]
+    torch.manual_seed(0)
+    model = DepthAnythingV2(**cfg).eval()
+    sd, shapes = load_synth(model)
+    with open(os.path.join(GOLD, f"schema_A_{enc}.json"), "w") as f:
+        json.dump({"params": [[k, list(s)] for k, s in shapes],
+                   "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
+    x_all = make_inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
+    hook = PreRelu(model.depth_head.scratch.output_conv2[2])
+    mem = O.MemoryState(6)
+    out = {"meta": np.array([B, steps, H, W, sub, SEED])}
+    worst = 0.0
+    for t in range(steps):
+        t0 = time.time()
+        with torch.no_grad():
+            feats = model.pretrained.get_intermediate_layers(x_all[t], model.intermediate_layer_idx[enc], return_class_token=True)
+            d = model(x_all[t])
+        pre = hook.val[-1][:, 0]
+        tr = {}
+        with torch.no_grad():
+            mine = O.depth_anything_v2_forward(sd, x_all[t], mem, enc, pre_relu=True, trace=tr)
+        e = relerr(mine, pre)
+        e2 = relerr(torch.relu(mine), d)
+        mf_ref = model.memory_block.memory_bank.get_memory()[-1]["memory_feature"]
+        e3 = relerr(mem.items[-1]["memory_feature"], mf_ref)
+        e4 = relerr(mem.items[-1]["memory_pos_enc"], model.memory_block.memory_bank.get_memory()[-1]["memory_pos_enc"])
+        worst = max(worst, e, e2, e3, e4)
+        print(f"[A {name}] step {t} S={min(t, 6)} ref {time.time() - t0:.1f}s pre-ReLU mean {pre.mean():.4f} std {pre.std():.4f} "
+              f"frac>0 {(pre > 0).float().mean():.3f} | oracle rel err pre {e:.2e} post {e2:.2e} memfeat {e3:.2e} mempos {e4:.2e}")
+        if t in keep:
+            out[f"pre_{t}"] = pre[:, ::sub, ::sub].numpy()
+            out[f"pre_stats_{t}"] = stats(pre)
+            for i, (pt, ct) in enumerate(feats):
+                idx, val = samples(pt)
+                out[f"tap{i}_stats_{t}"] = stats(pt)
+                out[f"tap{i}_samp_{t}"] = val
+            idx, val = samples(mf_ref)
+            out[f"memfeat_stats_{t}"] = stats(mf_ref)
+            out[f"memfeat_samp_{t}"] = val
+    assert worst <= 1e-5, worst
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+
+
+def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str):
+    from video_depth_anything.video_depth import VideoDepthAnything
+    from oracle import ref_cpu as O
+    cfg = O.MODEL_CONFIGS[enc]
+    torch.manual_seed(0)
+    model = VideoDepthAnything(**cfg).eval()
+    sd, shapes = load_synth(model)
+    with open(os.path.join(GOLD, f"schema_B_{enc}.json"), "w") as f:
+        json.dump({"params": [[k, list(s)] for k, s in shapes],
+                   "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
+    x = make_inputs(T, H, W).reshape(1, T, 3, H, W)
+    hook = PreRelu(model.head.scratch.output_conv2[2])
+    mm_out = []
+    hs = [m.register_forward_hook(lambda m, i, o: mm_out.append(o[0].detach().clone())) for m in model.head.motion_modules]
+    t0 = time.time()
+    with torch.no_grad():
+        d = model(x)
+    # the micro-batched tail calls output_conv2 T/4 times (dpt_temporal.py:113-125)
+    pre = torch.cat(hook.val, dim=0)[:, 0]
+    tr = {}
+    with torch.no_grad():
+        mine = O.video_depth_anything_forward(sd, x, enc, pre_relu=True, trace=tr)[0]
+    e = relerr(mine, pre)
+    e2 = relerr(torch.relu(mine), d[0])
+    print(f"[B {name}] T={T} ref {time.time() - t0:.1f}s pre-ReLU mean {pre.mean():.4f} std {pre.std():.4f} "
+          f"frac>0 {(pre > 0).float().mean():.3f} | oracle rel err pre {e:.2e} post {e2:.2e}")
+    out = {"meta": np.array([1, T, H, W, sub, SEED])}
+    out["pre_stats_all"] = np.stack([stats(pre[t]) for t in range(T)])
+    for t in keep:
+        out[f"pre_{t}"] = pre[t, ::sub, ::sub].numpy()
+    names = ["layer_3", "layer_4", "path_4", "path_3"]
+    for i, o in enumerate(mm_out):
+        # o: [b, c, f, h, w] -> compare against oracle [(b f), c, h, w]
+        o2 = o.permute(0, 2, 1, 3, 4).flatten(0, 1)
+        em = relerr(tr[names[i]], o2)
+        print(f"    motion_module[{i}] out {tuple(o2.shape)} std {o2.std():.3f} oracle rel err {em:.2e}")
+        assert em <= 1e-5
+        idx, val = samples(o2)
+        out[f"mm{i}_stats"] = stats(o2)
+        out[f"mm{i}_samp"] = val
+    assert max(e, e2) <= 1e-5
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+
+
+def gen_host():
+    """G7/G8: Resize.get_size table, scale/shift + blend, pos-embed interpolation, stitcher."""
+    from depth_anything_v2.util.transform import Resize
+    from depth_anything_v2.dinov2 import DINOv2
+    import utils.util as U
+    from oracle import ref_cpu as O
+    from vdn import synth
+    r = Resize(width=518, height=518, resize_target=False, keep_aspect_ratio=True, ensure_multiple_of=14,
+               resize_method="lower_bound", image_interpolation_method=2)
+    pairs = [(640, 480), (1920, 1080), (518, 518), (500, 375), (375, 500), (1280, 720), (720, 1280),
+             (224, 224), (1024, 1024), (854, 480), (333, 777), (2048, 858)]
+    sizes = np.array([list(p) + list(int(v) for v in r.get_size(*p)) for p in pairs])
+    for row in sizes:
+        assert O.get_size(int(row[0]), int(row[1])) == (int(row[2]), int(row[3])), row
+    pred = synth.normal(SEED, "ss_pred", (2, 40, 50)) * 3 + 5
+    targ = 1.7 * pred - 0.3 + 0.1 * synth.normal(SEED, "ss_noise", (2, 40, 50))
+    s, sh = U.compute_scale_and_shift(np.concatenate(list(pred)), np.concatenate(list(targ)),
+                                      np.concatenate(np.ones_like(targ) == 1))
+    s2, sh2 = O.compute_scale_and_shift(np.concatenate(list(pred)), np.concatenate(list(targ)),
+                                        np.concatenate(np.ones_like(targ) == 1))
+    assert (s, sh) == (s2, sh2)
+    pre = [synth.normal(SEED, f"ip{i}", (6, 7)) for i in range(8)]
+    post = [synth.normal(SEED, f"iq{i}", (6, 7)) for i in range(8)]
+    blend = np.stack(U.get_interpolate_frames(pre, post))
+    assert np.array_equal(blend, np.stack(O.get_interpolate_frames(pre, post)))
+    # pos-embed interpolation (dinov2.py:179-210) on vits for 224x224 and 392x518
+    torch.manual_seed(0)
+    vit = DINOv2("vits").eval()
+    pe = torch.from_numpy(synth.synth_param(SEED, "pretrained.pos_embed", (1, 1370, 384)))
+    vit.pos_embed.data.copy_(pe)
+    out = {"get_size": sizes, "scale_shift": np.array([s, sh], np.float64), "blend": blend}
+    for (h, w) in [(224, 224), (392, 518), (266, 266)]:
+        x = torch.zeros(1, (h // 14) * (w // 14) + 1, 384)
+        ref = vit.interpolate_pos_encoding(x, h, w).detach()
+        mine = O.interpolate_pos_encoding(pe, x.shape[1] - 1, h, w)
+        assert relerr(mine, ref) <= 1e-6
+        idx, val = samples(ref, 512)
+        out[f"pos_{h}x{w}_samp"] = val
+        out[f"pos_{h}x{w}_stats"] = stats(ref)
+    # window index table + stitcher on a 50-frame toy clip (exercises 3 windows)
+    n = 50
+    wins = O.window_inputs(n)
+    out["windows_50"] = np.array(wins)
+    np.savez_compressed(os.path.join(GOLD, "host.npz"), **out)
+    print("[host] get_size / scale_shift / blend / pos-embed fixtures written; oracle agrees")
+
+
+def gen_stitch():
+    """Run the reference's infer_video_depth windowing+stitching with a stub forward to pin
+    window_inputs()/stitch_windows() (video_depth.py:88-156) without the network."""
+    from video_depth_anything import video_depth as VD
+    from oracle import ref_cpu as O
+    from vdn import synth
+
+    n, h, w = 50, 28, 42
+
+    class Stub(VD.VideoDepthAnything):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.seen = []
+
+        def forward(self, x):
+            # depth = per-frame mean of the normalised input scaled by a per-window gain so that
+            # the stitcher has a real scale/shift to recover
+            g = 1.0 + 0.25 * len(self.seen)
+            self.seen.append(x[0, :, 0, 0, 0].clone())
+            return (x.mean(2) * g + 0.1 * len(self.seen)).abs()
+
+    frames = synth.frames_u8(SEED, n, h, w)
+    # identity Resize (the cv2 shim has no resize): patch Resize.__call__ to a no-op
+    from video_depth_anything.util import transform as T
+    T.Resize.__call__ = lambda self, s: s
+    stub = Stub()
+    import contextlib
+    torch.autocast = lambda **k: contextlib.nullcontext()  # CPU: autocast("cuda") is irrelevant
+    d, _ = stub.infer_video_depth(frames, 30, input_size=28, device="cpu", fp32=True)
+    # replay through the oracle's window table + stitcher
+    x = torch.from_numpy(synth.normalize_frames(frames))
+    wins = O.window_inputs(n)
+    dl = []
+    for wi, idxs in enumerate(wins):
+        g = 1.0 + 0.25 * wi
+        dep = (x[idxs].mean(1) * g + 0.1 * (wi + 1)).abs()
+        dl += [dep[i].numpy() for i in range(32)]
+    mine = O.stitch_windows(dl, n)
+    err = np.abs(mine - d).max() / np.abs(d).max()
+    print(f"[stitch] windows {len(wins)} rel max err oracle-vs-reference {err:.2e}")
+    assert err < 1e-5  # float64-vs-float32 input normalisation (transform.py:133-136) is the residue
+    np.savez_compressed(os.path.join(GOLD, "stitch.npz"), out=d.astype(np.float32), meta=np.array([n, h, w, SEED]))
+
+
+JOBS = {
+    "host": lambda: gen_host(),
+    "stitch": lambda: gen_stitch(),
+    "A_vits_518": lambda: gen_A("vits", 518, 518, 1, 8, [0, 1, 6, 7], 2, "A_vits_518"),
+    "A_vits_b2_266": lambda: gen_A("vits", 266, 266, 2, 3, [0, 1, 2], 1, "A_vits_b2_266"),
+    "B_vits_518": lambda: gen_B("vits", 518, 518, 32, [0, 13, 31], 2, "B_vits_518"),
+    "B_vits_392x518": lambda: gen_B("vits", 392, 518, 8, [0, 7], 2, "B_vits_392x518"),
+    "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 2, [0, 1], 4, "A_vitl_518"),
+    "B_vitl_518": lambda: gen_B("vitl", 518, 518, 4, [0, 3], 4, "B_vitl_518"),
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    install_shims()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    for k, fn in JOBS.items():
+        if a.only and k not in a.only:
+            continue
+        t0 = time.time()
+        fn()
+        print(f"== {k} done in {time.time() - t0:.1f}s")

@@ -1,0 +1,95 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA fragments per
+// /opt/skills/guides/cdna_hip_programming.md §3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vdn.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define VDN_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return -(1000 + (int)e__);        \
+  } while (0)
+
+template <int DT> struct Half;
+template <> struct Half<VDN_F16> {
+  using T = _Float16;
+  using V8 = f16x8;
+  using V4 = f16x4;
+  using V2 = f16x2;
+  static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Half<VDN_BF16> {
+  using T = __bf16;
+  using V8 = bf16x8;
+  using V4 = bf16x4;
+  using V2 = bf16x2;
+  static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ReLU on 8 packed 16-bit floats held as 4 dwords: clear every lane whose sign bit is set
+// (works for fp16 and bf16 alike; -0 -> +0, NaN with sign -> 0 which matches max(x,0) closely
+// enough for activations that are finite by construction).
+template <typename V8>
+__device__ __forceinline__ V8 relu8(V8 v) {
+  u32x4 u = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t s = u[i] & 0x80008000u;          // sign bits of both halves
+    uint32_t m = (s >> 15) * 0xFFFFu;         // 0xFFFF in each half whose sign is set
+    u[i] &= ~m;
+  }
+  return __builtin_bit_cast(V8, u);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {  // nn.GELU() default (exact erf form)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float load_as_float(const void* p, int dt, size_t i) {
+  if (dt == VDN_F32) return ((const float*)p)[i];
+  if (dt == VDN_F16) return (float)((const _Float16*)p)[i];
+  return (float)((const __bf16*)p)[i];
+}
+
+__device__ __forceinline__ void store_from_float(void* p, int dt, size_t i, float v) {
+  if (dt == VDN_F32) ((float*)p)[i] = v;
+  else if (dt == VDN_F16) ((_Float16*)p)[i] = (_Float16)v;
+  else ((__bf16*)p)[i] = (__bf16)v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// XCD-aware bijective block remap (guide §5 'XCD swizzle must be bijective'): blocks that share
+// blockIdx % 8 share an XCD/L2, so give each XCD a contiguous run of the logical tile order.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int xcd = orig & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
