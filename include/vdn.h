@@ -109,10 +109,12 @@ int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
  * writes out_h (half, optional) and out_f (f32, optional).
  * Replaces nn.LayerNorm at dinov2_layers/block.py:84,87 + dinov2.py:310 (eps 1e-6),
  * memory_attention.py:60,74,93,162 (eps 1e-5), motion_module.py:179,189 (eps 1e-5, with the
- * sinusoidal PE add of :211 fused as addtab), LayerNorm2d sam2_utils.py:148-153 on NHWC rows.    */
+ * sinusoidal PE add of :211 fused as addtab), LayerNorm2d sam2_utils.py:148-153 on NHWC rows.
+ *   out_group > 0 drops the first row of every `out_group` rows (the cls token, dinov2.py:312)
+ *   and writes the remaining rows compacted.                                                     */
 int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
                   const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
-                  void* out_h, int h_dt, float* out_f, vdn_stream stream);
+                  int out_group, void* out_h, int h_dt, float* out_f, vdn_stream stream);
 
 /* Fused attention forward, head_dim 64: out[b, q, h*64+e] = softmax(scale * Q K^T) V.
  *   Q  half [BH, nq_pad, 64] (rows >= nq never read), K half [BH, nk_pad, 64],
@@ -148,10 +150,12 @@ int vdn_patchify(int dt, const float* img, void* rows, int B, int H, int W, int 
 /* x[b*rows_per_b + row, :] = vec[:] (cls_token + pos_embed[0], dinov2.py:219-220)                */
 int vdn_fill_row(float* x, const float* vec, int B, int rows_per_b, int row, int C, vdn_stream stream);
 
-/* Bicubic (A=-0.75, align_corners=False, scale-factor coordinate map) resample of the
- * [gs,gs,C] pos_embed grid to [oh,ow,C] (dinov2.py:193-203).                                      */
-int vdn_bicubic_grid(const float* src, float* dst, int gs, int oh, int ow, int C, float sx, float sy,
-                     vdn_stream stream);
+/* Bicubic resample (A=-0.75, align_corners=False, src = (dst+0.5)/scale - 0.5, clamped taps) of a
+ * channels-last f32 [ih, iw, C] grid to [oh, ow, C]: torch's scale-factor bicubic used on the
+ * pos_embed grid (dinov2.py:193-203, scale_rows = sx, scale_cols = sy there) and the same
+ * kernel cv2.INTER_CUBIC applies to frames (util/transform.py:113).                               */
+int vdn_bicubic(const float* src, float* dst, int ih, int iw, int oh, int ow, int C, float scale_rows,
+                float scale_cols, vdn_stream stream);
 
 /* y = x + alpha * vec[c]  (memory_attention.py:141)                                               */
 int vdn_add_vec(const float* x, const float* vec, float alpha, float* y, int rows, int C, vdn_stream stream);
@@ -177,6 +181,8 @@ int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const floa
 
 /* misc */
 int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);
+size_t vdn_sizeof_gemm_desc(void);      /* layout probes for FFI bindings */
+size_t vdn_offsetof_gemm_zeros(void);
 const char* vdn_version(void);
 int vdn_arch_ok(void); /* 1 if device 0 is gfx950 */
 

@@ -1,0 +1,48 @@
+"""Shared helpers for the tests: synthetic state dicts keyed by the reference schema, inputs, metrics."""
+import json
+import os
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+
+
+def schema(which: str, enc: str):
+    with open(os.path.join(GOLD, f"schema_{which}_{enc}.json")) as f:
+        return json.load(f)
+
+
+@lru_cache(maxsize=4)
+def synth_sd(which: str, enc: str):
+    """Oracle-side state dict (CPU f32) with the synthetic weights the fixtures were made with."""
+    from vdn import synth
+    from oracle import ref_cpu as O
+    sch = schema(which, enc)
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict([(k, tuple(s)) for k, s in sch["params"]], SEED).items()}
+    for k, s in sch["buffers"]:
+        sd[k] = O.temporal_pe(s[-1], s[1])
+    return sd
+
+
+def inputs(n, h, w):
+    from vdn import synth
+    return torch.from_numpy(synth.normalize_frames(synth.frames_u8(SEED, n, h, w)))
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().reshape(-1)
+    b = torch.as_tensor(b).double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def sample_idx(numel, n=256):
+    return (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def stats(t):
+    t = torch.as_tensor(t).float()
+    return np.array([t.mean().item(), t.std().item(), t.abs().max().item()])

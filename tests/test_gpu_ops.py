@@ -1,0 +1,399 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 CPU statement of the same op
+on the same (half-rounded) inputs. Shapes are deliberately ragged (tails in M, N, K, keys, frames).
+Tolerances: half outputs carry one rounding (2^-11 fp16 / 2^-8 bf16 relative) on top of fp32
+accumulation-order noise."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from vdn.runtime import Runtime
+    from vdn import _abi
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    assert _abi.lib.vdn_arch_ok() == 1, "not a gfx950 device"
+    return Runtime(torch.device("cuda:0"), torch.float16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def h(t):  # half-rounded copy kept in f32 (what the kernel actually sees)
+    return t.half().float()
+
+
+def close(got, ref, tol):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    err = (got - ref).norm() / (ref.norm() + 1e-30)
+    mx = (got - ref).abs().max() / (ref.abs().max() + 1e-30)
+    assert err < tol and mx < 8 * tol, (float(err), float(mx))
+
+
+def _w(n, k, seed):
+    from vdn import pack
+    w = rnd(n, k, seed=seed, scale=1 / math.sqrt(k))
+    return w, pack.linear(w.to(DEV), torch.float16)
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 192, 200), (1370, 384, 384), (77, 32, 64), (130, 48, 1152), (257, 1024, 640)])
+def test_gemm_plain_bias_gelu(rt, M, N, K):
+    from vdn import _abi
+    a = h(rnd(M, K, seed=1))
+    w, wp = _w(N, K, 2)
+    b = rnd(N, seed=3)
+    ref = F.gelu(a @ h(w).t() + b)
+    out = torch.empty(M, N, device=DEV)
+    rt.gemm(a.half().to(DEV), wp, M, N, K, out=out, bias=b.to(DEV), act=_abi.ACT_GELU)
+    close(out, ref, 2e-5 * math.sqrt(K) / 8 + 1e-5)
+
+
+def test_gemm_layerscale_residual_inplace_and_half_out(rt):
+    M, N, K = 500, 256, 512
+    a = h(rnd(M, K, seed=4))
+    w, wp = _w(N, K, 5)
+    b, g = rnd(N, seed=6), rnd(N, seed=7)
+    x = rnd(M, N, seed=8)
+    ref = x + (a @ h(w).t() + b) * g
+    xd = x.clone().to(DEV)
+    rt.gemm(a.half().to(DEV), wp, M, N, K, out=xd, bias=b.to(DEV), gamma=g.to(DEV), res1=xd)
+    close(xd, ref, 1e-4)
+    r2 = h(rnd(M, N, seed=9))
+    oh = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    rt.gemm(a.half().to(DEV), wp, M, N, K, out=oh, bias=b.to(DEV), res1=x.to(DEV), res2=r2.half().to(DEV), rowadd=None)
+    close(oh, x + r2 + a @ h(w).t() + b, 1e-3)
+
+
+def test_gemm_patch_embed_row_remap_and_table(rt):
+    # tokens land after each image's cls row; pos table row = m % P + 1 (dinov2.py:219-220)
+    B, P, C, K = 3, 10, 64, 640
+    a = h(rnd(B * P, K, seed=10))
+    w, wp = _w(C, K, 11)
+    b = rnd(C, seed=12)
+    tab = rnd(P + 1, C, seed=13)
+    tok = torch.full((B * (P + 1), C), -7.0, device=DEV)
+    rt.gemm(a.half().to(DEV), wp, B * P, C, K, out=tok, bias=b.to(DEV), tab=tab.to(DEV), tab_mod=P, tab_off=1,
+            row_group=P, row_skip=1)
+    ref = torch.full((B, P + 1, C), -7.0)
+    ref[:, 1:] = (a @ h(w).t() + b).reshape(B, P, C) + tab[1:]
+    close(tok.reshape(B, P + 1, C), ref, 1e-4)
+
+
+def test_gemm_rowadd(rt):
+    M, N, K = 200, 128, 128
+    a = h(rnd(M, K, seed=14))
+    w, wp = _w(N, K, 15)
+    ra = rnd(M, seed=16)
+    out = torch.empty(M, N, device=DEV)
+    rt.gemm(a.half().to(DEV), wp, M, N, K, out=out, rowadd=ra.to(DEV))
+    close(out, a @ h(w).t() + ra[:, None], 1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,relu_a", [(2, 13, 11, 48, 64, 1, True), (1, 37, 37, 64, 256, 2, False),
+                                                      (2, 9, 20, 256, 32, 1, False), (1, 6, 5, 96, 48, 1, True)])
+def test_gemm_conv3x3(rt, B, H, W, Ci, Co, stride, relu_a):
+    from vdn import pack, _abi
+    x = h(rnd(B, H, W, Ci, seed=20))
+    w = rnd(Co, Ci, 3, 3, seed=21, scale=1 / math.sqrt(9 * Ci))
+    b = rnd(Co, seed=22)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r1 = h(rnd(B * OH * OW, Co, seed=23))
+    xin = F.relu(x) if relu_a else x
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), h(w), b, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ref = F.relu(ref) + r1
+    out = torch.empty(B * OH * OW, Co, device=DEV, dtype=torch.float16)
+    rt.gemm(x.half().to(DEV), pack.conv3x3(w.to(DEV), torch.float16), B * OH * OW, Co, 9 * Ci, out=out, bias=b.to(DEV),
+            act=_abi.ACT_RELU, relu_a=relu_a, res1=r1.half().to(DEV),
+            conv=dict(B=B, H=H, W=W, C=Ci, OH=OH, OW=OW, stride=stride))
+    close(out, ref, 1.5e-3)
+
+
+@pytest.mark.parametrize("k,Ci,Co", [(4, 48, 48), (2, 96, 96)])
+def test_gemm_conv_transpose(rt, k, Ci, Co):
+    from vdn import pack, _abi
+    B, H, W = 2, 5, 7
+    x = h(rnd(B, H, W, Ci, seed=30))
+    w = rnd(Ci, Co, k, k, seed=31, scale=1 / math.sqrt(Ci))
+    b = rnd(Co, seed=32)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2), h(w), b, stride=k).permute(0, 2, 3, 1)
+    wp, bp = pack.conv_transpose(w.to(DEV), b.to(DEV), torch.float16)
+    out = torch.empty(B, H * k, W * k, Co, device=DEV, dtype=torch.float16)
+    rt.gemm(x.half().to(DEV), wp, B * H * W, k * k * Co, Ci, out=out, bias=bp, store=_abi.ST_CONVT,
+            convt=dict(k=k, cout=Co, B=B, H=H, W=W))
+    close(out, ref, 1.5e-3)
+
+
+def test_gemm_geglu(rt):
+    from vdn import pack, _abi
+    M, c = 150, 64
+    a = h(rnd(M, c, seed=40))
+    w = rnd(8 * c, c, seed=41, scale=1 / math.sqrt(c))
+    b = rnd(8 * c, seed=42)
+    y = a @ h(w).t() + b
+    hh, gate = y.chunk(2, dim=-1)
+    ref = hh * F.gelu(gate)
+    wp, bp = pack.geglu(w.to(DEV), b.to(DEV), torch.float16)
+    out = torch.empty(M, 4 * c, device=DEV, dtype=torch.float16)
+    rt.gemm(a.half().to(DEV), wp, M, 8 * c, c, out=out, bias=bp, store=_abi.ST_GEGLU)
+    close(out, ref, 1.5e-3)
+
+
+def test_gemm_heads_qkv_split(rt):
+    from vdn import _abi
+    B, T, Hh = 2, 50, 6
+    C = Hh * 64
+    a = h(rnd(B * T, C, seed=50))
+    w, wp = _w(3 * C, C, 51)
+    b = rnd(3 * C, seed=52)
+    y = (a @ h(w).t() + b).reshape(B, T, 3, Hh, 64)
+    tp = 64
+    q = torch.zeros(B * Hh, tp, 64, device=DEV, dtype=torch.float16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B * Hh, 64, tp, device=DEV, dtype=torch.float16)
+    rt.gemm(a.half().to(DEV), wp, B * T, 3 * C, C, bias=b.to(DEV), store=_abi.ST_HEADS,
+            heads=dict(dst=[q, k, vt], transposed=[0, 0, 1], heads=Hh, tokens=T, tpad=tp))
+    close(q.reshape(B, Hh, tp, 64)[:, :, :T], y[:, :, 0].permute(0, 2, 1, 3), 1.5e-3)
+    close(k.reshape(B, Hh, tp, 64)[:, :, :T], y[:, :, 1].permute(0, 2, 1, 3), 1.5e-3)
+    close(vt.reshape(B, Hh, 64, tp)[:, :, :, :T], y[:, :, 2].permute(0, 2, 3, 1), 1.5e-3)
+    assert float(vt.reshape(B, Hh, 64, tp)[:, :, :, T:].abs().max()) == 0.0  # pad columns untouched
+
+
+def test_gemm_heads_rope_with_slot_offset(rt):
+    """k (rotated) + v^T into ring slot 1 of a 2-slot bank: sam2 position_encoding.py:212-239 semantics."""
+    from vdn import pack, _abi
+    from oracle import ref_cpu as O
+    B, side, Hh = 2, 5, 2
+    P, C = side * side, Hh * 64
+    a = h(rnd(B * P, C, seed=60))
+    wk, wv = rnd(C, C, seed=61, scale=1 / math.sqrt(C)), rnd(C, C, seed=62, scale=1 / math.sqrt(C))
+    bk, bv = rnd(C, seed=63), rnd(C, seed=64)
+    kk = (a @ h(wk).t() + bk).reshape(B, P, Hh, 64).transpose(1, 2)
+    vv = (a @ h(wv).t() + bv).reshape(B, P, Hh, 64).transpose(1, 2)
+    fc = O.compute_axial_cis(64, side, side)
+    _, kr = O.apply_rotary_enc(kk, kk, fc, False)
+    wp, bp = pack.cat_proj([wk.to(DEV), wv.to(DEV)], [bk.to(DEV), bv.to(DEV)], [1, 0], torch.float16)
+    cs = pack.rope_table(side, side, 64, device=DEV)
+    tp = 64
+    kd = torch.zeros(B * Hh, tp, 64, device=DEV, dtype=torch.float16)
+    vd = torch.zeros(B * Hh, 64, tp, device=DEV, dtype=torch.float16)
+    rt.gemm(a.half().to(DEV), wp, B * P, 2 * C, C, bias=bp, store=_abi.ST_HEADS,
+            heads=dict(dst=[kd, vd], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P,
+                       tok_off=P, tpad=tp))
+    close(kd.reshape(B, Hh, tp, 64)[:, :, P:2 * P], kr, 1.5e-3)
+    close(vd.reshape(B, Hh, 64, tp)[:, :, :, P:2 * P], vv.transpose(2, 3), 1.5e-3)
+    assert float(kd.reshape(B, Hh, tp, 64)[:, :, :P].abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C", [64, 384, 1024])
+def test_layernorm_variants(rt, C):
+    rows, grp = 30, 10
+    x = rnd(rows, C, seed=70) * 3 + 1
+    w, b = rnd(C, seed=71), rnd(C, seed=72)
+    vec, tab = rnd(C, seed=73), rnd(4, C, seed=74)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    oh = torch.empty(rows, C, device=DEV, dtype=torch.float16)
+    of = torch.empty(rows, C, device=DEV)
+    rt.layernorm(x.to(DEV), rows, C, w.to(DEV), b.to(DEV), 1e-6, out_h=oh, out_f=of)
+    close(of, ref, 1e-5)
+    close(oh, ref, 1e-3)
+    # + alpha*vec + table[(row / 5) % 4]
+    rt.layernorm(x.to(DEV), rows, C, w.to(DEV), b.to(DEV), 1e-5, out_f=of, addvec=vec.to(DEV), alpha=0.5,
+                 addtab=tab.to(DEV), tab_div=5, tab_mod=4)
+    idx = (torch.arange(rows) // 5) % 4
+    close(of, F.layer_norm(x, (C,), w, b, 1e-5) + 0.5 * vec + tab[idx], 1e-5)
+    # drop the first row of each group of 10 (cls token) and compact
+    oc = torch.empty(rows - rows // grp, C, device=DEV)
+    rt.layernorm(x.to(DEV), rows, C, w.to(DEV), b.to(DEV), 1e-6, out_f=oc, out_group=grp)
+    keep = [r for r in range(rows) if r % grp != 0]
+    close(oc, ref[keep], 1e-5)
+    # half input
+    xh = h(x)
+    rt.layernorm(xh.half().to(DEV), rows, C, w.to(DEV), b.to(DEV), 1e-6, out_f=of)
+    close(of, F.layer_norm(xh, (C,), w, b, 1e-6), 1e-5)
+
+
+@pytest.mark.parametrize("F_,HW,C", [(3, 50, 192), (2, 1369, 256), (2, 361, 1024), (1, 100, 64)])
+def test_groupnorm(rt, F_, HW, C):
+    x = h(rnd(F_, HW, C, seed=80) * 2 + 0.5)
+    w, b = rnd(C, seed=81), rnd(C, seed=82)
+    ref = F.group_norm(x.permute(0, 2, 1).reshape(F_, C, HW, 1), 32, w, b, 1e-6).reshape(F_, C, HW).permute(0, 2, 1)
+    y = torch.empty(F_, HW, C, device=DEV, dtype=torch.float16)
+    rt.groupnorm(x.half().to(DEV), y, F_, HW, C, 32, w.to(DEV), b.to(DEV), 1e-6)
+    close(y, ref, 1.5e-3)
+
+
+# --------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,nq,nk", [(2, 3, 150, 200), (1, 2, 1370, 1370), (1, 1, 37, 64), (2, 2, 129, 2738)])
+def test_flash_attention(rt, B, H, nq, nk):
+    from vdn.runtime import ceil_to
+    q, k, v = h(rnd(B, H, nq, 64, seed=90)), h(rnd(B, H, nk, 64, seed=91)), h(rnd(B, H, nk, 64, seed=92))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, nq, H * 64)
+    qp, kp = ceil_to(nq, 64), ceil_to(nk, 64)
+    qd = torch.zeros(B * H, qp, 64, device=DEV, dtype=torch.float16)
+    kd = torch.full((B * H, kp, 64), float("nan"), device=DEV, dtype=torch.float16)  # pad rows must not matter
+    vd = torch.zeros(B * H, 64, kp, device=DEV, dtype=torch.float16)
+    qd[:, :nq] = q.reshape(B * H, nq, 64).half().to(DEV)
+    kd[:, :nk] = k.reshape(B * H, nk, 64).half().to(DEV)
+    vd[:, :, :nk] = v.reshape(B * H, nk, 64).transpose(1, 2).half().to(DEV)
+    out = torch.empty(B, nq, H * 64, device=DEV, dtype=torch.float16)
+    rt.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
+    close(out, ref, 2e-3)
+
+
+def test_flash_attention_online_max_rescale(rt):
+    """A key whose score jumps far above the running max in a LATE tile forces the rescale branch."""
+    nq, nk = 64, 320
+    q, k, v = h(rnd(1, 1, nq, 64, seed=93)), h(rnd(1, 1, nk, 64, seed=94)), h(rnd(1, 1, nk, 64, seed=95))
+    k[0, 0, 290] = q[0, 0, 5] * 6.0   # spike for query 5 in the last tile
+    k[0, 0, 10] = q[0, 0, 9] * 6.0    # and an early spike for query 9
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, nq, 64)
+    vd = v.reshape(1, nk, 64).transpose(1, 2).contiguous().half().to(DEV)
+    out = torch.empty(1, nq, 64, device=DEV, dtype=torch.float16)
+    rt.flash_attn(q.reshape(1, nq, 64).half().to(DEV), k.reshape(1, nk, 64).half().to(DEV), vd, out, 1, 1, nq, nq, nk, nk, 0.125)
+    close(out, ref, 2e-3)
+
+
+@pytest.mark.parametrize("Bv,T,D,c", [(2, 32, 9, 64), (1, 7, 5, 192), (1, 32, 3, 1024), (2, 4, 6, 256), (1, 1, 4, 384)])
+def test_temporal_attention(rt, Bv, T, D, c):
+    heads, dh = 8, c // 8
+    qkv = h(rnd(Bv * T, D, 3 * c, seed=100))
+    x = qkv.reshape(Bv, T, D, 3, heads, dh).permute(3, 0, 2, 4, 1, 5)  # [3, b, d, head, f, e]
+    ref = F.scaled_dot_product_attention(x[0], x[1], x[2])              # softmax over frames
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(Bv * T, D, c)
+    out = torch.empty(Bv * T, D, c, device=DEV, dtype=torch.float16)
+    rt.temporal_attn(qkv.half().to(DEV), out, Bv, T, D, c, heads, dh ** -0.5)
+    close(out, ref, 2e-3)
+
+
+# --------------------------------------------------------------------------------------------- spatial
+def test_upsample_bilinear_align_corners(rt):
+    B, C = 2, 64
+    for (ih, iw, oh, ow) in [(19, 19, 37, 37), (37, 28, 74, 56), (296, 296, 518, 518), (5, 7, 5, 7)]:
+        b = 1 if oh > 200 else B
+        x = h(rnd(b, ih, iw, C, seed=110))
+        ref = F.interpolate(x.permute(0, 3, 1, 2), (oh, ow), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+        y = torch.empty(b, oh, ow, C, device=DEV, dtype=torch.float16)
+        rt.upsample(x.half().to(DEV), y, b, ih, iw, oh, ow, C)
+        close(y, ref, 1e-3)
+    x = rnd(2, 30, 41, seed=111)
+    ref = F.relu(F.interpolate(x[:, None], (77, 50), mode="bilinear", align_corners=True)[:, 0])
+    y = torch.empty(2, 77, 50, device=DEV)
+    rt.upsample_f32(x.to(DEV), y, 2, 30, 41, 77, 50, relu=True)
+    close(y, ref, 1e-5)
+
+
+def test_patchify_fill_row_addvec_cast(rt):
+    B, H, W = 2, 28, 42
+    img = rnd(B, 3, H, W, seed=120)
+    rows = torch.empty(B * 2 * 3, 640, device=DEV, dtype=torch.float16)
+    rt.patchify(img.to(DEV), rows, B, H, W, 640)
+    ref = F.unfold(img, 14, stride=14).transpose(1, 2).reshape(B * 6, 588)  # (c,ky,kx) order == conv weight order
+    close(rows[:, :588], h(ref), 1e-6)
+    assert float(rows[:, 588:].abs().max()) == 0.0
+    x = torch.zeros(B * 5, 16, device=DEV)
+    vec = rnd(16, seed=121)
+    rt.fill_row(x, vec.to(DEV), B, 5, 0, 16)
+    close(x.reshape(B, 5, 16)[:, 0], vec.expand(B, 16), 1e-7)
+    assert float(x.reshape(B, 5, 16)[:, 1:].abs().max()) == 0.0
+    a = rnd(12, 16, seed=122)
+    y = torch.empty(12, 16, device=DEV)
+    rt.add_vec(a.to(DEV), vec.to(DEV), 0.1, y, 12, 16)
+    close(y, a + 0.1 * vec, 1e-6)
+    z = torch.empty(12, 16, device=DEV, dtype=torch.float16)
+    rt.cast(a.to(DEV), z)
+    close(z, a.half(), 1e-6)
+
+
+@pytest.mark.parametrize("oh,ow", [(16, 16), (28, 37), (19, 19), (40, 31)])
+def test_bicubic_matches_torch_scale_factor_semantics(rt, oh, ow):
+    """interpolate_pos_encoding (dinov2.py:193-203): scale_factor=((oh+0.1)/37, (ow+0.1)/37), bicubic."""
+    C, gs = 24, 37
+    g = rnd(gs, gs, C, seed=130)
+    sx, sy = (oh + 0.1) / gs, (ow + 0.1) / gs
+    ref = F.interpolate(g.permute(2, 0, 1)[None], scale_factor=(sx, sy), mode="bicubic")[0].permute(1, 2, 0)
+    assert ref.shape[:2] == (oh, ow)
+    y = torch.empty(oh, ow, C, device=DEV)
+    rt.bicubic(g.to(DEV), y, gs, gs, oh, ow, C, sx, sy)
+    close(y, ref, 1e-5)
+
+
+def test_head_out(rt):
+    M, C = 1000, 32
+    f = F.relu(h(rnd(M, C, seed=140)))
+    w = rnd(C, seed=141)
+    ref = f @ w + 0.3
+    d = torch.empty(M, device=DEV)
+    rt.head_out(f.half().to(DEV), w.to(DEV), 0.3, d, M, C, relu=False)
+    close(d, ref, 1e-5)
+    rt.head_out(f.half().to(DEV), w.to(DEV), 0.3, d, M, C, relu=True)
+    close(d, F.relu(ref), 1e-5)
+
+
+def test_mask_downsampler_stages(rt):
+    from oracle import ref_cpu as O
+    B, H, W = 2, 266, 266
+    depth = F.relu(rnd(B, 1, H, W, seed=150))
+    p = {}
+    e0 = dict(w0=rnd(4, 1, 3, 3, seed=151), b0=rnd(4, seed=152), lw=rnd(4, seed=153) + 1, lb=rnd(4, seed=154), w3=rnd(1, 4, 1, 1, seed=155), b3=rnd(1, seed=156))
+    e1 = dict(w0=rnd(49, 1, 7, 7, seed=157, scale=0.2), b0=rnd(49, seed=158), lw=rnd(49, seed=159) + 1, lb=rnd(49, seed=160), w3=rnd(1, 49, 1, 1, seed=161), b3=rnd(1, seed=162))
+    m = torch.sigmoid(depth)
+    m = F.conv2d(m, e0["w0"], e0["b0"], stride=2, padding=1)
+    m = F.conv2d(F.gelu(O.layer_norm_2d(m, e0["lw"], e0["lb"])), e0["w3"], e0["b3"])
+    ref1 = m
+    m = F.conv2d(m, e1["w0"], e1["b0"], stride=7)
+    ref2 = F.conv2d(F.gelu(O.layer_norm_2d(m, e1["lw"], e1["lb"])), e1["w3"], e1["b3"])
+    flat = lambda e: torch.cat([e[k].reshape(-1) for k in ("w0", "b0", "lw", "lb", "w3", "b3")]).to(DEV)
+    h1, w1 = ref1.shape[-2:]
+    h2, w2 = ref2.shape[-2:]
+    o1 = torch.empty(B, h1, w1, device=DEV)
+    rt.mask_down1(depth[:, 0].contiguous().to(DEV), o1, B, H, W, h1, w1, flat(e0))
+    close(o1, ref1[:, 0], 1e-5)
+    o2 = torch.empty(B, h2, w2, device=DEV)
+    rt.mask_down2(o1, o2, B, h1, w1, h2, w2, flat(e1))
+    close(o2, ref2[:, 0], 1e-4)
+
+
+def test_dwconv7(rt):
+    B, H, W, C = 2, 9, 11, 64
+    x = rnd(B, H, W, C, seed=170)
+    w, b = rnd(C, 1, 7, 7, seed=171, scale=0.15), rnd(C, seed=172)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=3, groups=C).permute(0, 2, 3, 1)
+    y = torch.empty(B, H, W, C, device=DEV)
+    rt.dwconv7(x.to(DEV), y, B, H, W, C, w.reshape(C, 49).t().contiguous().to(DEV), b.to(DEV))
+    close(y, ref, 1e-5)
+
+
+def test_bf16_operand_mode(rt):
+    """The same GEMM / attention kernels instantiated for bf16 operands (VDN_HALF=bf16 mode)."""
+    from vdn.runtime import Runtime
+    from vdn import pack
+    rb = Runtime(torch.device("cuda:0"), torch.bfloat16)
+    M, N, K = 200, 128, 256
+    a = rnd(M, K, seed=180).bfloat16().float()
+    w = (rnd(N, K, seed=181) / 16).bfloat16().float()
+    out = torch.empty(M, N, device=DEV)
+    rb.gemm(a.bfloat16().to(DEV), pack.linear(w.to(DEV), torch.bfloat16), M, N, K, out=out)
+    close(out, a @ w.t(), 1e-4)
+    nq = nk = 100
+    q, k, v = [rnd(1, 2, nq, 64, seed=s).bfloat16().float() for s in (182, 183, 184)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, nq, 128)
+    kd = torch.zeros(2, 128, 64, device=DEV, dtype=torch.bfloat16)
+    vd = torch.zeros(2, 64, 128, device=DEV, dtype=torch.bfloat16)
+    kd[:, :nk] = k[0].bfloat16().to(DEV)
+    vd[:, :, :nk] = v[0].transpose(1, 2).bfloat16().to(DEV)
+    o = torch.empty(1, nq, 128, device=DEV, dtype=torch.bfloat16)
+    rb.flash_attn(q[0].bfloat16().contiguous().to(DEV), kd, vd, o, 1, 2, nq, nq, nk, 128, 0.125)
+    close(o, ref, 1.5e-2)

@@ -1,0 +1,125 @@
+"""Host logic of the product package + the C-ABI surface (no GPU compute)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLD, ROOT, schema
+
+
+def test_get_size_table_matches_reference(golden_dir):
+    from vdn import util
+    g = np.load(os.path.join(golden_dir, "host.npz"))
+    for w, h, nw, nh in g["get_size"]:
+        assert util.get_size(int(w), int(h)) == (int(nw), int(nh))
+
+
+def test_window_table_and_stitch_match_reference(golden_dir):
+    from vdn import synth, util
+    g = np.load(os.path.join(golden_dir, "host.npz"))
+    assert np.array_equal(np.array(util.window_table(50)), g["windows_50"])
+    s = np.load(os.path.join(golden_dir, "stitch.npz"))
+    n, h, w, seed = [int(v) for v in s["meta"]]
+    x = synth.normalize_frames(synth.frames_u8(seed, n, h, w))
+    dl = []
+    for wi, idxs in enumerate(util.window_table(n)):
+        dep = np.abs(x[idxs].mean(1) * (1.0 + 0.25 * wi) + 0.1 * (wi + 1))
+        dl += [dep[i] for i in range(32)]
+    out = util.stitch(dl, n)
+    assert np.abs(out - s["out"]).max() / np.abs(s["out"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 22, 23, 32, 33, 256])
+def test_window_table_structure(n):
+    """slot 0 is always frame 0; window count = ceil(n/22); 256 frames -> 12 windows."""
+    from vdn import util
+    t = util.window_table(n)
+    assert len(t) == -(-n // 22)
+    assert all(len(w) == 32 for w in t)
+    assert all(w[0] == 0 for w in t)
+    assert max(max(w) for w in t) == n - 1
+    if n == 256:
+        assert len(t) == 12
+
+
+def test_scale_shift_and_blend(golden_dir):
+    from vdn import synth, util
+    g = np.load(os.path.join(golden_dir, "host.npz"))
+    pred = synth.normal(1234, "ss_pred", (2, 40, 50)) * 3 + 5
+    targ = 1.7 * pred - 0.3 + 0.1 * synth.normal(1234, "ss_noise", (2, 40, 50))
+    s, sh = util.compute_scale_and_shift(np.concatenate(list(pred)), np.concatenate(list(targ)),
+                                         np.concatenate(np.ones_like(targ) == 1))
+    assert np.allclose([s, sh], g["scale_shift"], rtol=1e-6)
+    pre = [synth.normal(1234, f"ip{i}", (6, 7)) for i in range(8)]
+    post = [synth.normal(1234, f"iq{i}", (6, 7)) for i in range(8)]
+    assert np.array_equal(np.stack(util.get_interpolate_frames(pre, post)), g["blend"])
+    # degenerate system -> identity (utils/util.py:52-60)
+    z = np.zeros((4, 4), np.float32)
+    assert util.compute_scale_and_shift(z, z, np.zeros_like(z)) == (1, 0)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/vdn.h <-> libvdn_hip.so <-> vdn/_abi.py agree (load + symbols only, no launches)."""
+    from vdn import _abi
+    hdr = open(os.path.join(ROOT, "include", "vdn.h")).read()
+    declared = set(re.findall(r"\b(vdn_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vdn_stream"}
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(_abi.lib, name), f"{name} declared in vdn.h but not exported"
+    assert declared == set(_abi.EXPORTS), (declared ^ set(_abi.EXPORTS))
+    assert _abi.lib.vdn_sizeof_gemm_desc() == ctypes.sizeof(_abi.GemmDesc)
+    assert _abi.lib.vdn_offsetof_gemm_zeros() == _abi.GemmDesc.zeros.offset
+    assert b"gfx950" in _abi.lib.vdn_version()
+
+
+def test_gemm_argument_validation_without_gpu():
+    """vdn_gemm rejects malformed descriptors before touching the device."""
+    from vdn import _abi
+    d = _abi.GemmDesc()
+    assert _abi.lib.vdn_gemm(ctypes.byref(d), None) == -1            # empty
+    d.M, d.N, d.K, d.A, d.W, d.zeros = 8, 8, 12, 16, 16, 16          # K % 8 != 0
+    d.ldb = 64
+    assert _abi.lib.vdn_gemm(ctypes.byref(d), None) == -3
+    d.K, d.lda, d.dt = 16, 16, 2                                      # f32 operands unsupported
+    assert _abi.lib.vdn_gemm(ctypes.byref(d), None) == -2
+
+
+@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitl"), ("B", "vits"), ("B", "vitl")])
+def test_state_dict_schema_matches_reference(which, enc):
+    """Drop-in contract: same parameter/buffer keys and shapes as the reference classes."""
+    import vdn
+    cls = vdn.DepthAnythingV2 if which == "A" else vdn.VideoDepthAnything
+    m = cls(**vdn.MODEL_CONFIGS[enc])
+    sch = schema(which, enc)
+    assert {k: tuple(v.shape) for k, v in m.named_parameters()} == {k: tuple(s) for k, s in sch["params"]}
+    assert {k: tuple(v.shape) for k, v in m.named_buffers()} == {k: tuple(s) for k, s in sch["buffers"]}
+    sd = m.state_dict()
+    m.load_state_dict(sd, strict=True)
+
+
+def test_product_refuses_cpu():
+    import vdn
+    m = vdn.DepthAnythingV2(**vdn.MODEL_CONFIGS["vits"])
+    with pytest.raises(Exception):
+        m.forward(torch.zeros(1, 3, 28, 28))
+
+
+def test_packing_permutations():
+    from vdn import pack
+    p = pack.rope_perm(128, "cpu")
+    assert sorted(p.tolist()) == list(range(128))
+    # head 0: packed tile 0 = even columns of pairs 0..15, tile 1 = their odd partners
+    assert p[:16].tolist() == [2 * i for i in range(16)] and p[16:32].tolist() == [2 * i + 1 for i in range(16)]
+    assert p[32:48].tolist() == [32 + 2 * i for i in range(16)]
+    w = torch.arange(64 * 4, dtype=torch.float32).reshape(64, 4)
+    b = torch.arange(64, dtype=torch.float32)
+    wp, bp = pack.geglu(w, b, torch.float16)
+    assert bp[:16].tolist() == list(range(16)) and bp[16:32].tolist() == list(range(32, 48))
+    assert wp.shape == (64, 64)
+    cs = pack.rope_table(3, 3, 64)
+    assert cs.shape == (9, 32, 2) and torch.allclose(cs[0, :, 0], torch.ones(32))

@@ -1,0 +1,86 @@
+"""The oracle (oracle/ref_cpu.py) against fixtures produced by the IMPORTED reference
+(tools/make_golden.py, build container only). This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLD, inputs, rel_l2, sample_idx, synth_sd
+from oracle import ref_cpu as O
+
+TOL = 2e-5
+
+
+def _run_A(name, enc, check_steps=None):
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    B, steps, H, W, sub, _ = [int(v) for v in g["meta"]]
+    sd = synth_sd("A", enc)
+    x = inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
+    mem = O.MemoryState(6)
+    kept = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("pre_") and not k.startswith("pre_stats"))
+    last = max(kept) if check_steps is None else max(check_steps)
+    with torch.no_grad():
+        for t in range(last + 1):
+            tr = {}
+            pre = O.depth_anything_v2_forward(sd, x[t], mem, enc, pre_relu=True, trace=tr)
+            if t in kept and (check_steps is None or t in check_steps):
+                assert rel_l2(pre[:, ::sub, ::sub], g[f"pre_{t}"]) < TOL, (name, t)
+                for i, (pt, _) in enumerate(tr["taps"]):
+                    idx = sample_idx(pt.numel())
+                    assert rel_l2(pt.reshape(-1)[idx], g[f"tap{i}_samp_{t}"]) < TOL
+                mf = mem.items[-1]["memory_feature"]
+                assert rel_l2(mf.reshape(-1)[sample_idx(mf.numel())], g[f"memfeat_samp_{t}"]) < TOL
+
+
+def test_oracle_A_vits_stream_fills_and_evicts():
+    # 8-frame stream: memory depth 0..6, then eviction at frame 7 (memory_bank.py:17-20)
+    _run_A("A_vits_518", "vits")
+
+
+def test_oracle_A_vits_batch2_nonstandard_grid():
+    # 266x266 (19x19 grid): bicubic pos-embed path (dinov2.py:179-210), batch of 2 streams
+    _run_A("A_vits_b2_266", "vits")
+
+
+def _run_B(name, enc):
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    _, T, H, W, sub, _ = [int(v) for v in g["meta"]]
+    sd = synth_sd("B", enc)
+    x = inputs(T, H, W).reshape(1, T, 3, H, W)
+    tr = {}
+    with torch.no_grad():
+        pre = O.video_depth_anything_forward(sd, x, enc, pre_relu=True, trace=tr)[0]
+    for k in g.files:
+        if k.startswith("pre_") and k != "pre_stats_all":
+            t = int(k.split("_")[1])
+            assert rel_l2(pre[t, ::sub, ::sub], g[k]) < TOL, (name, t)
+    for i, nm in enumerate(["layer_3", "layer_4", "path_4", "path_3"]):
+        v = tr[nm]
+        assert rel_l2(v.reshape(-1)[sample_idx(v.numel())], g[f"mm{i}_samp"]) < TOL
+    means = np.array([pre[t].mean().item() for t in range(T)])
+    assert np.allclose(means, g["pre_stats_all"][:, 0], rtol=1e-3, atol=1e-4)
+
+
+def test_oracle_B_vits_full_window():
+    _run_B("B_vits_518", "vits")
+
+
+def test_oracle_B_vits_nonsquare():
+    _run_B("B_vits_392x518", "vits")
+
+
+def test_oracle_A_vitl():
+    _run_A("A_vitl_518", "vitl", check_steps=[0])
+
+
+def test_oracle_host_pieces():
+    g = np.load(os.path.join(GOLD, "host.npz"))
+    for w, h, nw, nh in g["get_size"]:
+        assert O.get_size(int(w), int(h)) == (int(nw), int(nh))
+    assert np.array_equal(np.array(O.window_inputs(50)), g["windows_50"])
+    from vdn import synth
+    pe = torch.from_numpy(synth.synth_param(1234, "pretrained.pos_embed", (1, 1370, 384)))
+    for (h, w) in [(224, 224), (392, 518), (266, 266)]:
+        out = O.interpolate_pos_encoding(pe, (h // 14) * (w // 14), h, w)
+        assert rel_l2(out.reshape(-1)[sample_idx(out.numel(), 512)], g[f"pos_{h}x{w}_samp"]) < 1e-6

@@ -156,107 +156,138 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
     __syncthreads();
   }
 
-  // ---- epilogue (fp32)
-  const int nb = n0 + wn * WTN;  // first column of this wave's tile
+  // ---- epilogue: accumulators -> LDS (fp32 tile) -> fused fp32 math -> wide row stores.
+  // The K loop ended with a barrier, so the staging buffers are free to be reused.
+  constexpr int LDT = BN + 4;  // padded fp32 row (floats)
+  float* tileC = (float*)smem;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * WTM + i * 16 + fq * 4 + j;
-      if (m >= p.M) continue;
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        tileC[(wm * WTM + i * 16 + fq * 4 + j) * LDT + wn * WTN + t * 16 + fr] = acc[i][t][j];
+  __syncthreads();
+
+  constexpr int CG = BN / 4;  // 4-column groups per tile row
+  if (p.store == VDN_ST_PLAIN || p.store == VDN_ST_CONVT) {
+    for (int idx = tid; idx < BM * CG; idx += 256) {
+      const int r = idx / CG, c = (idx - r * CG) * 4;
+      const int m = m0 + r, n = n0 + c;
+      if (m >= p.M || n >= p.N) continue;
+      const f32x4 a = *(const f32x4*)(tileC + r * LDT + c);
+      float v[4] = {a[0], a[1], a[2], a[3]};
       const float radd = p.rowadd ? p.rowadd[m] : 0.f;
-      const size_t tab_row = p.tab ? (size_t)(m % p.tab_mod + p.tab_off) * p.N : 0;
-      if (p.store == VDN_ST_GEGLU) {
-        if constexpr ((TN & 1) == 0) {
 #pragma unroll
-        for (int t = 0; t < TN; t += 2) {
-          const int nh = nb + t * 16 + fr, ng = nh + 16;
-          if (ng >= p.N) continue;
-          const float h = acc[i][t][j] + (p.bias ? p.bias[nh] : 0.f);
-          const float g = acc[i][t + 1][j] + (p.bias ? p.bias[ng] : 0.f);
-          const int nc = ((nb + t * 16) >> 1) + fr;
-          store_from_float(p.out, p.out_dt, (size_t)m * p.ldc + nc, h * gelu_erf(g));
-        }
-        }
-        continue;
+      for (int e = 0; e < 4; ++e) {
+        if (p.bias) v[e] += p.bias[n + e];
+        v[e] += radd;
+        if (p.act == VDN_ACT_GELU) v[e] = gelu_erf(v[e]);
+        else if (p.act == VDN_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+        if (p.gamma) v[e] *= p.gamma[n + e];
+        if (p.tab) v[e] += p.tab[(size_t)(m % p.tab_mod + p.tab_off) * p.N + n + e];
+        if (p.res1) v[e] += load_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n + e);
+        if (p.res2) v[e] += load_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n + e);
       }
-      if (p.store == VDN_ST_HEADS) {
-        const int bt = m / p.tokens;
-        const int tl = m - bt * p.tokens;
-        const int tk = tl + p.tok_off;
-        const int hc = p.heads * 64;
-        const int split = nb / hc;
-        const int head = (nb - split * hc) >> 6;
-        if (nb >= p.N) continue;
-        T* dst = (T*)p.dst[split];
-        const size_t hb = ((size_t)bt * p.heads + head);
-        if constexpr (TN == 4) {
-          if (p.rope[split]) {
-            const float* cs = p.rope_cs + (size_t)(tl % p.rope_mod) * 64;
-#pragma unroll
-            for (int t = 0; t < 4; t += 2) {
-              const int pi = (t << 3) + fr;  // pair index 0..31
-              float re = acc[i][t][j] + (p.bias ? p.bias[nb + t * 16 + fr] : 0.f);
-              float im = acc[i][t + 1][j] + (p.bias ? p.bias[nb + t * 16 + 16 + fr] : 0.f);
-              const float c = cs[2 * pi], s = cs[2 * pi + 1];
-              const float ore = re * c - im * s, oim = re * s + im * c;
-              if (p.transposed[split]) {
-                dst[(hb * 64 + 2 * pi) * p.tpad + tk] = (T)ore;
-                dst[(hb * 64 + 2 * pi + 1) * p.tpad + tk] = (T)oim;
-              } else {
-                typename H::V2 pr = {(T)ore, (T)oim};
-                *(typename H::V2*)(dst + (hb * p.tpad + tk) * 64 + 2 * pi) = pr;
-              }
-            }
-            continue;
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-          const int e = t * 16 + fr;
-          const int n = nb + e;
-          if (n >= p.N) continue;
-          const float v = acc[i][t][j] + (p.bias ? p.bias[n] : 0.f);
-          if (p.transposed[split]) dst[(hb * 64 + e) * p.tpad + tk] = (T)v;
-          else dst[(hb * p.tpad + tk) * 64 + e] = (T)v;
-        }
-        continue;
-      }
-      // PLAIN / CONVT share the arithmetic
-      size_t orow;
-      int cb = 0, cy = 0, cx = 0;
+      size_t o;
       if (p.store == VDN_ST_CONVT) {
         const int hw = p.cH * p.cW;
-        cb = m / hw;
-        const int rem = m - cb * hw;
-        cy = rem / p.cW;
-        cx = rem - cy * p.cW;
-        orow = 0;
+        const int cb = m / hw, rem = m - cb * hw;
+        const int cy = rem / p.cW, cx = rem - cy * p.cW;
+        const int kk = n / p.cout, co = n - kk * p.cout;  // cout % 4 == 0: the group stays in one tap
+        const int ky = kk / p.ck, kx = kk - ky * p.ck;
+        o = (((size_t)cb * (p.cH * p.ck) + cy * p.ck + ky) * (p.cW * p.ck) + cx * p.ck + kx) * p.cout + co;
       } else {
-        orow = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc;
+        o = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc + n;
       }
+      if (p.out_dt == VDN_F32) {
+        *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        typename H::V4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        *(typename H::V4*)((T*)p.out + o) = h;
+      }
+    }
+  } else if (p.store == VDN_ST_GEGLU) {
+    // packed columns: 16-wide blocks alternate [h | gate]; output column nc <- (h, gate) pair
+    for (int idx = tid; idx < BM * (CG / 2); idx += 256) {
+      const int r = idx / (CG / 2), oc = (idx - r * (CG / 2)) * 4;  // output column inside the tile
+      const int ch = (oc >> 4) * 32 + (oc & 15);                     // packed h column inside the tile
+      const int m = m0 + r;
+      if (m >= p.M || n0 + ch + 16 >= p.N) continue;
+      const f32x4 hh = *(const f32x4*)(tileC + r * LDT + ch);
+      const f32x4 gg = *(const f32x4*)(tileC + r * LDT + ch + 16);
+      float v[4];
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int n = nb + t * 16 + fr;
-        if (n >= p.N) continue;
-        float v = acc[i][t][j];
-        if (p.bias) v += p.bias[n];
-        v += radd;
-        if (p.act == VDN_ACT_GELU) v = gelu_erf(v);
-        else if (p.act == VDN_ACT_RELU) v = fmaxf(v, 0.f);
-        if (p.gamma) v *= p.gamma[n];
-        if (p.tab) v += p.tab[tab_row + n];
-        if (p.res1) v += load_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n);
-        if (p.res2) v += load_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n);
-        size_t o;
-        if (p.store == VDN_ST_CONVT) {
-          const int kk = n / p.cout, co = n - kk * p.cout;
-          const int ky = kk / p.ck, kx = kk - ky * p.ck;
-          o = (((size_t)cb * (p.cH * p.ck) + cy * p.ck + ky) * (p.cW * p.ck) + cx * p.ck + kx) * p.cout + co;
-        } else {
-          o = orow + n;
+      for (int e = 0; e < 4; ++e) {
+        const float hv = hh[e] + (p.bias ? p.bias[n0 + ch + e] : 0.f);
+        const float gv = gg[e] + (p.bias ? p.bias[n0 + ch + 16 + e] : 0.f);
+        v[e] = hv * gelu_erf(gv);
+      }
+      const size_t o = (size_t)m * p.ldc + (n0 >> 1) + oc;
+      if (p.out_dt == VDN_F32) {
+        *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        typename H::V4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        *(typename H::V4*)((T*)p.out + o) = h;
+      }
+    }
+  } else {  // VDN_ST_HEADS
+    const int hc = p.heads * 64;
+    // pass 1: token-major splits, one thread = 4 columns (plain) or 4 rotated pairs (RoPE)
+    for (int idx = tid; idx < BM * CG; idx += 256) {
+      const int r = idx / CG, c = (idx - r * CG) * 4;
+      const int m = m0 + r, n = n0 + c;
+      if (m >= p.M || n >= p.N) continue;
+      const int split = n / hc;
+      if (p.transposed[split]) continue;
+      const int head = (n - split * hc) >> 6, e0 = n & 63;
+      const int bt = m / p.tokens, tl = m - bt * p.tokens;
+      T* dst = (T*)p.dst[split] + (((size_t)bt * p.heads + head) * p.tpad + tl + p.tok_off) * 64;
+      const f32x4 a = *(const f32x4*)(tileC + r * LDT + c);
+      if (p.rope[split]) {
+        if (e0 & 16) continue;  // imaginary tile: consumed by the thread owning the real tile
+        const f32x4 b = *(const f32x4*)(tileC + r * LDT + c + 16);
+        const int pi = ((e0 >> 5) << 4) + (e0 & 15);  // first of 4 consecutive pair indices
+        const float* cs = p.rope_cs + (size_t)(tl % p.rope_mod) * 64 + 2 * pi;
+        typename H::V8 o8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float re = a[e] + (p.bias ? p.bias[n + e] : 0.f);
+          const float im = b[e] + (p.bias ? p.bias[n + 16 + e] : 0.f);
+          const float cc = cs[2 * e], ss = cs[2 * e + 1];
+          o8[2 * e] = (T)(re * cc - im * ss);
+          o8[2 * e + 1] = (T)(re * ss + im * cc);
         }
-        store_from_float(p.out, p.out_dt, o, v);
+        *(typename H::V8*)(dst + 2 * pi) = o8;
+      } else {
+        typename H::V4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (T)(a[e] + (p.bias ? p.bias[n + e] : 0.f));
+        *(typename H::V4*)(dst + e0) = h;
+      }
+    }
+    // pass 2: dim-major (V^T) splits, one thread = 4 consecutive tokens of one column, so that
+    // neighbouring threads write neighbouring tokens of the same [64, tpad] row
+    bool any_t = false;
+    for (int i = 0; i < p.nsplit; ++i) any_t |= (p.transposed[i] != 0);
+    if (any_t) {
+      constexpr int RG = BM / 4;
+      for (int idx = tid; idx < BN * RG; idx += 256) {
+        const int c = idx / RG, r = (idx - c * RG) * 4;
+        const int n = n0 + c;
+        if (n >= p.N) continue;
+        const int split = n / hc;
+        if (!p.transposed[split]) continue;
+        const int head = (n - split * hc) >> 6, e = n & 63;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        T* dst = (T*)p.dst[split];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m = m0 + r + k;
+          if (m >= p.M) break;
+          const int bt = m / p.tokens, tl = m - bt * p.tokens;
+          dst[(((size_t)bt * p.heads + head) * 64 + e) * p.tpad + tl + p.tok_off] = (T)(tileC[(r + k) * LDT + c] + bv);
+        }
       }
     }
   }
@@ -265,7 +296,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
 template <int DT, int BM, int BN, int WM, int WN>
 int launch_tile(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+  const size_t stage2 = 2 * (size_t)(BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 4;
+  const size_t lds = stage2 > ctile ? stage2 : ctile;
   const bool conv = d.a_mode == VDN_A_CONV3X3;
   const int amode = conv ? (d.relu_a ? 2 : 1) : (d.relu_a ? 3 : 0);
   switch (amode) {
@@ -303,18 +335,22 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   } else {
     return VDN_EUNSUPPORTED;
   }
+  if (d.N & 3) return VDN_EALIGN;  // the epilogue stores 4 columns per lane
   switch (d.store) {
     case VDN_ST_PLAIN:
       if (!d.out || d.ldc < d.N) return VDN_EINVAL;
+      if ((d.ldc & 3) || ((uintptr_t)d.out & 15)) return VDN_EALIGN;
       break;
     case VDN_ST_GEGLU:
       if (!d.out || (d.N & 31) || d.ldc < d.N / 2 || d.act || d.gamma || d.res1 || d.res2 || d.tab || d.rowadd)
         return VDN_EINVAL;
+      if ((d.ldc & 3) || ((uintptr_t)d.out & 15)) return VDN_EALIGN;
       break;
     case VDN_ST_CONVT:
       if (!d.out || d.ck <= 0 || d.cout <= 0 || d.N != d.ck * d.ck * d.cout || d.M != d.cB * d.cH * d.cW || d.res1 ||
           d.res2 || d.tab)
         return VDN_EINVAL;
+      if ((d.cout & 3) || ((uintptr_t)d.out & 15)) return VDN_EALIGN;
       break;
     case VDN_ST_HEADS:
       if (d.nsplit < 1 || d.nsplit > 3 || d.heads <= 0 || d.N != d.nsplit * d.heads * 64 || d.tokens <= 0 ||
@@ -322,7 +358,7 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
           d.tab || d.rowadd)
         return VDN_EINVAL;
       for (int i = 0; i < d.nsplit; ++i) {
-        if (!d.dst[i]) return VDN_EINVAL;
+        if (!d.dst[i] || ((uintptr_t)d.dst[i] & 15)) return VDN_EINVAL;
         if (d.rope[i] && (!d.rope_cs || d.rope_mod <= 0)) return VDN_EINVAL;
       }
       break;

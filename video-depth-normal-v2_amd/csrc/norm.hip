@@ -1,0 +1,267 @@
+// Normalisation / elementwise kernels (HBM-bound; one pass over the data, 8-16 B per lane).
+#include "common.hpp"
+
+namespace {
+
+template <typename XT> struct Vec4;
+template <> struct Vec4<float> { using V = f32x4; };
+template <> struct Vec4<_Float16> { using V = f16x4; };
+template <> struct Vec4<__bf16> { using V = bf16x4; };
+
+// ---------------------------------------------------------------- LayerNorm: one wave per row
+template <typename XT, int DT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, int rows, int C,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, const float* __restrict__ addvec, float alpha,
+                                                        const float* __restrict__ addtab, int tab_div, int tab_mod,
+                                                        int out_group, typename Half<DT>::T* __restrict__ out_h,
+                                                        float* __restrict__ out_f) {
+  using T = typename Half<DT>::T;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  // out_group > 0: drop the first row of every group (the cls token) and compact the rest
+  if (out_group > 0 && row % out_group == 0) return;
+  const size_t orow = out_group > 0 ? (size_t)(row - row / out_group - 1) : (size_t)row;
+  const XT* xr = x + (size_t)row * C;
+  constexpr int NV = 8;  // up to 8 x 256 = 2048 channels, 4 per lane per step
+  float v[NV][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < C) {
+      const typename Vec4<XT>::V xv = *(const typename Vec4<XT>::V*)(xr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = (float)xv[e];
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  const float* tab = addtab ? addtab + (size_t)((row / tab_div) % tab_mod) * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < C) {
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = (v[i][e] - mean) * rstd * w[c + e] + b[c + e];
+        if (addvec) y[e] += alpha * addvec[c + e];
+        if (tab) y[e] += tab[c + e];
+      }
+      if (out_f) *(f32x4*)(out_f + orow * C + c) = f32x4{y[0], y[1], y[2], y[3]};
+      if (out_h) {
+        typename Half<DT>::V4 hv = {(T)y[0], (T)y[1], (T)y[2], (T)y[3]};
+        *(typename Half<DT>::V4*)(out_h + orow * C + c) = hv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm (NHWC), 2 kernels
+// stats: grid (F, nsplit); deterministic: per-channel column sums in fixed order, then per group.
+template <int DT>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const typename Half<DT>::T* __restrict__ x, int HW,
+                                                              int C, int groups, float* __restrict__ partial,
+                                                              int nsplit) {
+  using V8 = typename Half<DT>::V8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int f = blockIdx.x, sp = blockIdx.y;
+  const int cv = C >> 3;              // 8-channel vectors per pixel
+  const int pl = 256 / cv;            // pixel lanes (>= 1 because C <= 2048)
+  const int tid = threadIdx.x;
+  const int my_pl = tid / cv, my_cv = tid - my_pl * cv;
+  const int p0 = (int)(((long long)HW * sp) / nsplit), p1 = (int)(((long long)HW * (sp + 1)) / nsplit);
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+  if (my_pl < pl) {
+    const typename Half<DT>::T* xb = x + (size_t)f * HW * C + my_cv * 8;
+    for (int p = p0 + my_pl; p < p1; p += pl) {
+      const V8 v = *(const V8*)(xb + (size_t)p * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float fv = (float)v[e];
+        s[e] += fv;
+        ss[e] += fv * fv;
+      }
+    }
+  }
+  float* col = (float*)smem;  // [pl][C][2]
+  if (my_pl < pl) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      col[((size_t)my_pl * C + my_cv * 8 + e) * 2] = s[e];
+      col[((size_t)my_pl * C + my_cv * 8 + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  const int cg = C / groups;
+  for (int g = tid; g < groups; g += 256) {
+    float a = 0.f, bq = 0.f;
+    for (int k = 0; k < pl; ++k)
+      for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        a += col[((size_t)k * C + c) * 2];
+        bq += col[((size_t)k * C + c) * 2 + 1];
+      }
+    float* o = partial + (((size_t)f * nsplit + sp) * groups + g) * 2;
+    o[0] = a;
+    o[1] = bq;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const typename Half<DT>::T* __restrict__ x,
+                                                              typename Half<DT>::T* __restrict__ y, int HW, int C,
+                                                              int groups, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float eps,
+                                                              const float* __restrict__ partial, int nsplit) {
+  using T = typename Half<DT>::T;
+  using V8 = typename Half<DT>::V8;
+  __shared__ float mr[2 * 64];
+  const int f = blockIdx.x;
+  const int cg = C / groups;
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+      const float* pp = partial + (((size_t)f * nsplit + k) * groups + g) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+    const float n = (float)HW * (float)cg;
+    const float mean = a / n;
+    const float var = fmaxf(q / n - mean * mean, 0.f);
+    mr[2 * g] = mean;
+    mr[2 * g + 1] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const size_t nvec = (size_t)HW * (C >> 3);
+  const size_t per = (nvec + gridDim.y - 1) / gridDim.y;
+  const size_t v0 = per * blockIdx.y, v1 = (v0 + per < nvec) ? v0 + per : nvec;
+  const T* xb = x + (size_t)f * HW * C;
+  T* yb = y + (size_t)f * HW * C;
+  const int cv = C >> 3;
+  for (size_t i = v0 + threadIdx.x; i < v1; i += 256) {
+    const int c0 = (int)(i % cv) * 8;
+    const V8 v = *(const V8*)(xb + i * 8);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e, g = c / cg;
+      o[e] = (T)(((float)v[e] - mr[2 * g]) * mr[2 * g + 1] * w[c] + b[c]);
+    }
+    *(V8*)(yb + i * 8) = o;
+  }
+}
+
+__global__ void add_vec_kernel(const float* __restrict__ x, const float* __restrict__ vec, float alpha,
+                               float* __restrict__ y, size_t n4, int C) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const f32x4 a = *(const f32x4*)(x + i * 4);
+    const f32x4 v = *(const f32x4*)(vec + c);
+    *(f32x4*)(y + i * 4) = f32x4{a[0] + alpha * v[0], a[1] + alpha * v[1], a[2] + alpha * v[2], a[3] + alpha * v[3]};
+  }
+}
+
+__global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restrict__ y, int ydt, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store_from_float(y, ydt, i, load_as_float(x, xdt, i));
+}
+
+template <typename XT>
+int ln_launch(const void* x, int rows, int C, const float* w, const float* b, float eps, const float* addvec,
+              float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, int h_dt,
+              float* out_f, hipStream_t s) {
+  const dim3 grid((rows + 3) / 4);
+  if (h_dt == VDN_BF16)
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, out_f);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, out_f);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+}  // namespace
+
+extern "C" int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
+                             const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
+                             int out_group, void* out_h, int h_dt, float* out_f, vdn_stream stream) {
+  if (!x || !w || !b || rows <= 0 || C <= 0 || (!out_h && !out_f)) return VDN_EINVAL;
+  if ((C & 3) || C > 2048) return VDN_EALIGN;
+  if (addtab && (tab_div <= 0 || tab_mod <= 0)) return VDN_EINVAL;
+  if (out_h && h_dt != VDN_F16 && h_dt != VDN_BF16) return VDN_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (!addtab) { tab_div = 1; tab_mod = 1; }
+  switch (x_dt) {
+    case VDN_F32: return ln_launch<float>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, h_dt, out_f, s);
+    case VDN_F16: return ln_launch<_Float16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, h_dt, out_f, s);
+    case VDN_BF16: return ln_launch<__bf16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, h_dt, out_f, s);
+    default: return VDN_EUNSUPPORTED;
+  }
+}
+
+extern "C" int vdn_groupnorm(int dt, const void* x, void* y, int F, int HW, int C, int groups, const float* w,
+                             const float* b, float eps, float* partial, int nsplit, vdn_stream stream) {
+  if (!x || !y || !w || !b || !partial || F <= 0 || HW <= 0 || groups <= 0 || groups > 64 || C % groups || nsplit <= 0)
+    return VDN_EINVAL;
+  if ((C & 7) || C > 2048) return VDN_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int pl = 256 / (C >> 3);
+  const size_t lds = (size_t)pl * C * 2 * sizeof(float);
+  const int chunks = (int)(((size_t)HW * (C >> 3) + 256 * 8 - 1) / (256 * 8));
+  if (dt == VDN_F16) {
+    hipLaunchKernelGGL(groupnorm_stats_kernel<VDN_F16>, dim3(F, nsplit), dim3(256), lds, s, (const _Float16*)x, HW, C,
+                       groups, partial, nsplit);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<VDN_F16>, dim3(F, chunks), dim3(256), 0, s, (const _Float16*)x,
+                       (_Float16*)y, HW, C, groups, w, b, eps, partial, nsplit);
+  } else if (dt == VDN_BF16) {
+    hipLaunchKernelGGL(groupnorm_stats_kernel<VDN_BF16>, dim3(F, nsplit), dim3(256), lds, s, (const __bf16*)x, HW, C,
+                       groups, partial, nsplit);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<VDN_BF16>, dim3(F, chunks), dim3(256), 0, s, (const __bf16*)x,
+                       (__bf16*)y, HW, C, groups, w, b, eps, partial, nsplit);
+  } else {
+    return VDN_EUNSUPPORTED;
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_add_vec(const float* x, const float* vec, float alpha, float* y, int rows, int C,
+                           vdn_stream stream) {
+  if (!x || !vec || !y || rows <= 0 || C <= 0) return VDN_EINVAL;
+  if (C & 3) return VDN_EALIGN;
+  const size_t n4 = (size_t)rows * C / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(add_vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, vec, alpha, y, n4, C);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream) {
+  if (!x || !y || n == 0) return VDN_EINVAL;
+  if (x_dt < 0 || x_dt > VDN_F32 || y_dt < 0 || y_dt > VDN_F32) return VDN_EUNSUPPORTED;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_dt, y, y_dt, n);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}

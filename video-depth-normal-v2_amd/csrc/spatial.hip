@@ -1,0 +1,415 @@
+// Spatial / gather kernels (HBM-bound): bilinear resize, patchify, pos-embed bicubic, depth tail,
+// MaskDownSampler stages, depthwise 7x7.
+#include "common.hpp"
+#include <stddef.h>
+
+namespace {
+
+// PyTorch's align_corners=True source index: scale = (in-1)/(out-1) in float, src = scale * dst
+__device__ __forceinline__ void ac_coord(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  i0 = i0 < in - 1 ? i0 : in - 1;
+  i1 = i0 < in - 1 ? i0 + 1 : i0;
+  l1 = src - (float)i0;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void upsample_kernel(const typename Half<DT>::T* __restrict__ x,
+                                                       typename Half<DT>::T* __restrict__ y, int B, int IH, int IW,
+                                                       int OH, int OW, int C) {
+  using T = typename Half<DT>::T;
+  using V8 = typename Half<DT>::V8;
+  const int cv = C >> 3;
+  const size_t total = (size_t)B * OH * OW * cv;
+  const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+  const float sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cv);
+    size_t pix = i / cv;
+    const int ox = (int)(pix % OW);
+    pix /= OW;
+    const int oy = (int)(pix % OH);
+    const int b = (int)(pix / OH);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    ac_coord(oy, sy, IH, y0, y1, ly);
+    ac_coord(ox, sx, IW, x0, x1, lx);
+    const T* xb = x + (size_t)b * IH * IW * C + c8 * 8;
+    const V8 v00 = *(const V8*)(xb + ((size_t)y0 * IW + x0) * C);
+    const V8 v01 = *(const V8*)(xb + ((size_t)y0 * IW + x1) * C);
+    const V8 v10 = *(const V8*)(xb + ((size_t)y1 * IW + x0) * C);
+    const V8 v11 = *(const V8*)(xb + ((size_t)y1 * IW + x1) * C);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float top = (1.f - lx) * (float)v00[e] + lx * (float)v01[e];
+      const float bot = (1.f - lx) * (float)v10[e] + lx * (float)v11[e];
+      o[e] = (T)((1.f - ly) * top + ly * bot);
+    }
+    *(V8*)(y + i * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                           int IH, int IW, int OH, int OW, int relu) {
+  const size_t total = (size_t)B * OH * OW;
+  const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+  const float sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    const size_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    ac_coord(oy, sy, IH, y0, y1, ly);
+    ac_coord(ox, sx, IW, x0, x1, lx);
+    const float* xb = x + (size_t)b * IH * IW;
+    const float top = (1.f - lx) * xb[y0 * IW + x0] + lx * xb[y0 * IW + x1];
+    const float bot = (1.f - lx) * xb[y1 * IW + x0] + lx * xb[y1 * IW + x1];
+    float v = (1.f - ly) * top + ly * bot;
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
+                                                       typename Half<DT>::T* __restrict__ rows, int B, int H, int W,
+                                                       int ldk) {
+  using T = typename Half<DT>::T;
+  using V8 = typename Half<DT>::V8;
+  const int ph = H / 14, pw = W / 14;
+  const int kv = ldk >> 3;
+  const size_t total = (size_t)B * ph * pw * kv;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k8 = (int)(i % kv);
+    size_t row = i / kv;
+    const int px = (int)(row % pw);
+    const size_t t = row / pw;
+    const int py = (int)(t % ph);
+    const int b = (int)(t / ph);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k8 * 8 + e;
+      float v = 0.f;
+      if (k < 588) {
+        const int c = k / 196, rem = k - c * 196;
+        const int ky = rem / 14, kx = rem - ky * 14;
+        v = img[(((size_t)b * 3 + c) * H + py * 14 + ky) * W + px * 14 + kx];
+      }
+      o[e] = (T)v;
+    }
+    *(V8*)(rows + i * 8) = o;
+  }
+}
+
+__global__ void fill_row_kernel(float* __restrict__ x, const float* __restrict__ vec, int B, int rows_per_b, int row,
+                                int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  x[((size_t)b * rows_per_b + row) * C + c] = vec[c];
+}
+
+// torch upsample_bicubic2d (A = -0.75), align_corners=False with an explicit scale factor:
+// src = (dst + 0.5) / scale - 0.5, border-clamped taps.
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ void bicubic_kernel(const float* __restrict__ src, float* __restrict__ dst, int ih, int iw, int oh, int ow,
+                               int C, float inv_sy, float inv_sx) {
+  const size_t total = (size_t)oh * ow * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    const int ox = (int)(p % ow), oy = (int)(p / ow);
+    const float fy = ((float)oy + 0.5f) * inv_sy - 0.5f;
+    const float fx = ((float)ox + 0.5f) * inv_sx - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - (float)iy, wy);
+    cubic_w(fx - (float)ix, wx);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = iy - 1 + a;
+      yy = yy < 0 ? 0 : (yy > ih - 1 ? ih - 1 : yy);
+      float rowv = 0.f;
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+        int xx = ix - 1 + bq;
+        xx = xx < 0 ? 0 : (xx > iw - 1 ? iw - 1 : xx);
+        rowv += wx[bq] * src[((size_t)yy * iw + xx) * C + c];
+      }
+      acc += wy[a] * rowv;
+    }
+    dst[i] = acc;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void head_out_kernel(const typename Half<DT>::T* __restrict__ feat,
+                                                       const float* __restrict__ w, float bias,
+                                                       float* __restrict__ depth, int M, int C, int relu) {
+  using V8 = typename Half<DT>::V8;
+  __shared__ float sw[64];
+  if (threadIdx.x < C) sw[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  for (size_t m = blockIdx.x * (size_t)256 + threadIdx.x; m < (size_t)M; m += (size_t)gridDim.x * 256) {
+    float acc = bias;
+    for (int c = 0; c < C; c += 8) {
+      const V8 v = *(const V8*)(feat + m * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += sw[c + e] * (float)v[e];
+    }
+    depth[m] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+// sigmoid -> conv3x3 s2 p1 (1->4) -> LayerNorm2d(4, eps 1e-6) -> GELU -> conv1x1 (4->1)
+// w: [conv w 4x9 | conv b 4 | ln w 4 | ln b 4 | proj w 4 | proj b 1]
+__global__ __launch_bounds__(256) void mask_down1_kernel(const float* __restrict__ depth, float* __restrict__ out,
+                                                         int B, int H, int W, int OH, int OW,
+                                                         const float* __restrict__ w) {
+  __shared__ float sw[53];
+  if (threadIdx.x < 53) sw[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const size_t total = (size_t)B * OH * OW;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    const size_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        float v = 0.f;  // zero padding applies to sigmoid(depth), i.e. the padded value is 0
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = 1.f / (1.f + expf(-depth[((size_t)b * H + iy) * W + ix]));
+        in[ky * 3 + kx] = v;
+      }
+    float ch[4], mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float a = sw[36 + c];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a += sw[c * 9 + k] * in[k];
+      ch[c] = a;
+      mean += a;
+    }
+    mean *= 0.25f;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) var += (ch[c] - mean) * (ch[c] - mean);
+    const float rstd = 1.f / sqrtf(var * 0.25f + 1e-6f);
+    float o = sw[52];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o += sw[48 + c] * gelu_erf((ch[c] - mean) * rstd * sw[40 + c] + sw[44 + c]);
+    out[i] = o;
+  }
+}
+
+// conv7x7 s7 (1->49) -> LayerNorm2d(49) -> GELU -> conv1x1 (49->1)
+// w: [conv w 49x49 | conv b 49 | ln w 49 | ln b 49 | proj w 49 | proj b 1]
+__global__ __launch_bounds__(128) void mask_down2_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                         int H, int W, int OH, int OW, const float* __restrict__ w) {
+  __shared__ float sw[2598];
+  for (int i = threadIdx.x; i < 2598; i += 128) sw[i] = w[i];
+  __syncthreads();
+  const size_t i = blockIdx.x * (size_t)128 + threadIdx.x;
+  if (i >= (size_t)B * OH * OW) return;
+  const int ox = (int)(i % OW);
+  const size_t t = i / OW;
+  const int oy = (int)(t % OH);
+  const int b = (int)(t / OH);
+  float px[49];
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) px[ky * 7 + kx] = in[((size_t)b * H + oy * 7 + ky) * W + ox * 7 + kx];
+  float ch[49], mean = 0.f;
+#pragma unroll
+  for (int c = 0; c < 49; ++c) {
+    float a = sw[2401 + c];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) a += sw[c * 49 + k] * px[k];
+    ch[c] = a;
+    mean += a;
+  }
+  mean *= (1.f / 49.f);
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < 49; ++c) var += (ch[c] - mean) * (ch[c] - mean);
+  const float rstd = 1.f / sqrtf(var * (1.f / 49.f) + 1e-6f);
+  float o = sw[2597];
+#pragma unroll
+  for (int c = 0; c < 49; ++c)
+    o += sw[2548 + c] * gelu_erf((ch[c] - mean) * rstd * sw[2450 + c] + sw[2499 + c]);
+  out[i] = o;
+}
+
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                      int W, int C, const float* __restrict__ w,
+                                                      const float* __restrict__ bias) {
+  const int cv = C >> 2;
+  const size_t total = (size_t)B * H * W * cv;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % cv) * 4;
+    size_t p = i / cv;
+    const int ox = (int)(p % W);
+    p /= W;
+    const int oy = (int)(p % H);
+    const int b = (int)(p / H);
+    f32x4 acc = *(const f32x4*)(bias + c4);
+    for (int ky = 0; ky < 7; ++ky) {
+      const int iy = oy - 3 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ix = ox - 3 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = *(const f32x4*)(x + (((size_t)b * H + iy) * W + ix) * C + c4);
+        const f32x4 wv = *(const f32x4*)(w + (size_t)(ky * 7 + kx) * C + c4);
+        acc += v * wv;
+      }
+    }
+    *(f32x4*)(y + i * 4) = acc;
+  }
+}
+
+inline int grid_for(size_t work, int cap = 4096) {
+  const size_t b = (work + 255) / 256;
+  return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int vdn_upsample_bilinear(int dt, const void* x, void* y, int B, int IH, int IW, int OH, int OW, int C,
+                                     vdn_stream stream) {
+  if (!x || !y || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0) return VDN_EINVAL;
+  if ((C & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VDN_EALIGN;
+  const int g = grid_for((size_t)B * OH * OW * (C >> 3), 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == VDN_F16)
+    hipLaunchKernelGGL(upsample_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, (const _Float16*)x, (_Float16*)y, B, IH, IW,
+                       OH, OW, C);
+  else if (dt == VDN_BF16)
+    hipLaunchKernelGGL(upsample_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y, B, IH, IW, OH,
+                       OW, C);
+  else
+    return VDN_EUNSUPPORTED;
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_upsample_bilinear_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int relu,
+                                         vdn_stream stream) {
+  if (!x || !y || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return VDN_EINVAL;
+  hipLaunchKernelGGL(upsample_f32_kernel, dim3(grid_for((size_t)B * OH * OW)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     B, IH, IW, OH, OW, relu);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_patchify(int dt, const float* img, void* rows, int B, int H, int W, int ldk, vdn_stream stream) {
+  if (!img || !rows || B <= 0 || H <= 0 || W <= 0 || H % 14 || W % 14) return VDN_EINVAL;
+  if (ldk < 588 || (ldk & 63) || ((uintptr_t)rows & 15)) return VDN_EALIGN;
+  const int g = grid_for((size_t)B * (H / 14) * (W / 14) * (ldk >> 3), 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == VDN_F16)
+    hipLaunchKernelGGL(patchify_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, img, (_Float16*)rows, B, H, W, ldk);
+  else if (dt == VDN_BF16)
+    hipLaunchKernelGGL(patchify_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, img, (__bf16*)rows, B, H, W, ldk);
+  else
+    return VDN_EUNSUPPORTED;
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_fill_row(float* x, const float* vec, int B, int rows_per_b, int row, int C, vdn_stream stream) {
+  if (!x || !vec || B <= 0 || rows_per_b <= 0 || row < 0 || row >= rows_per_b || C <= 0) return VDN_EINVAL;
+  hipLaunchKernelGGL(fill_row_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, vec, B,
+                     rows_per_b, row, C);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_bicubic(const float* src, float* dst, int ih, int iw, int oh, int ow, int C, float scale_rows,
+                           float scale_cols, vdn_stream stream) {
+  if (!src || !dst || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || C <= 0 || scale_rows <= 0.f || scale_cols <= 0.f)
+    return VDN_EINVAL;
+  hipLaunchKernelGGL(bicubic_kernel, dim3(grid_for((size_t)oh * ow * C)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     ih, iw, oh, ow, C, 1.0f / scale_rows, 1.0f / scale_cols);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_head_out(int dt, const void* feat, const float* w, float bias, float* depth, int M, int C, int relu,
+                            vdn_stream stream) {
+  if (!feat || !w || !depth || M <= 0 || C <= 0 || C > 64) return VDN_EINVAL;
+  if ((C & 7) || ((uintptr_t)feat & 15)) return VDN_EALIGN;
+  const int g = grid_for((size_t)M, 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == VDN_F16)
+    hipLaunchKernelGGL(head_out_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, (const _Float16*)feat, w, bias, depth, M, C,
+                       relu);
+  else if (dt == VDN_BF16)
+    hipLaunchKernelGGL(head_out_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, (const __bf16*)feat, w, bias, depth, M, C,
+                       relu);
+  else
+    return VDN_EUNSUPPORTED;
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_mask_down1(const float* depth, float* out, int B, int H, int W, int OH, int OW, const float* w,
+                              vdn_stream stream) {
+  if (!depth || !out || !w || B <= 0 || OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1) return VDN_EINVAL;
+  hipLaunchKernelGGL(mask_down1_kernel, dim3(grid_for((size_t)B * OH * OW)), dim3(256), 0, (hipStream_t)stream, depth,
+                     out, B, H, W, OH, OW, w);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_mask_down2(const float* in, float* out, int B, int H, int W, int OH, int OW, const float* w,
+                              vdn_stream stream) {
+  if (!in || !out || !w || B <= 0 || OH != (H - 7) / 7 + 1 || OW != (W - 7) / 7 + 1 || OH <= 0 || OW <= 0)
+    return VDN_EINVAL;
+  const size_t total = (size_t)B * OH * OW;
+  hipLaunchKernelGGL(mask_down2_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, in,
+                     out, B, H, W, OH, OW, w);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const float* w, const float* bias,
+                           vdn_stream stream) {
+  if (!x || !y || !w || !bias || B <= 0 || H <= 0 || W <= 0 || C <= 0) return VDN_EINVAL;
+  if (C & 3) return VDN_EALIGN;
+  hipLaunchKernelGGL(dwconv7_kernel, dim3(grid_for((size_t)B * H * W * (C >> 2), 16384)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, B, H, W, C, w, bias);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" size_t vdn_sizeof_gemm_desc(void) { return sizeof(vdn_gemm_desc); }
+extern "C" size_t vdn_offsetof_gemm_zeros(void) { return offsetof(vdn_gemm_desc, zeros); }
+
+extern "C" const char* vdn_version(void) { return "vdn-hip 0.1 (gfx950)"; }
+
+extern "C" int vdn_arch_ok(void) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+  const char* a = prop.gcnArchName;
+  return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

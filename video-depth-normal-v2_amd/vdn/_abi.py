@@ -1,0 +1,93 @@
+"""ctypes binding of libvdn_hip.so (include/vdn.h). No CPU fallback: if the HIP library is missing
+or cannot be loaded, importing this module raises with the build command."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG, "lib", "libvdn_hip.so")
+
+F16, BF16, F32, NONE = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+A_PLAIN, A_CONV3X3 = 0, 1
+ST_PLAIN, ST_HEADS, ST_CONVT, ST_GEGLU = 0, 1, 2, 3
+
+i32, vp, fp = C.c_int32, C.c_void_p, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    """Mirror of vdn_gemm_desc (include/vdn.h) — field order and types must match exactly;
+    tests/test_abi.py checks sizeof/offsetof against the library's own probes."""
+    _fields_ = [
+        ("dt", i32), ("M", i32), ("N", i32), ("K", i32),
+        ("A", vp), ("a_mode", i32), ("lda", i32), ("relu_a", i32),
+        ("cB", i32), ("cH", i32), ("cW", i32), ("cC", i32), ("cOH", i32), ("cOW", i32), ("cstride", i32),
+        ("W", vp), ("ldb", i32),
+        ("bias", fp), ("rowadd", fp), ("act", i32), ("gamma", fp), ("tab", fp), ("tab_mod", i32), ("tab_off", i32),
+        ("res1", vp), ("res1_dt", i32), ("ldr1", i32),
+        ("res2", vp), ("res2_dt", i32), ("ldr2", i32),
+        ("store", i32), ("out", vp), ("out_dt", i32), ("ldc", i32), ("row_group", i32), ("row_skip", i32),
+        ("dst", vp * 3), ("nsplit", i32), ("heads", i32), ("tokens", i32), ("tok_off", i32), ("tpad", i32),
+        ("transposed", i32 * 3), ("rope", i32 * 3),
+        ("rope_cs", fp), ("rope_mod", i32),
+        ("ck", i32), ("cout", i32), ("zeros", vp),
+    ]
+
+
+class VdnError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (there is no CPU fallback). "
+            f"Build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).")
+    try:
+        return C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ImportError(f"cannot load {LIB_PATH}: {e}. Rebuild with `python __graft_entry__.py build`.") from e
+
+
+lib = _load()
+
+EXPORTS = {
+    "vdn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "vdn_layernorm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_float, fp, C.c_int, C.c_int,
+                                C.c_int, vp, C.c_int, fp, vp]),
+    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, vp]),
+    "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_int, vp]),
+    "vdn_upsample_bilinear": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_upsample_bilinear_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_patchify": (C.c_int, [C.c_int, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_fill_row": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_bicubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+    "vdn_add_vec": (C.c_int, [fp, fp, C.c_float, fp, C.c_int, C.c_int, vp]),
+    "vdn_head_out": (C.c_int, [C.c_int, vp, fp, C.c_float, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_mask_down1": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
+    "vdn_mask_down2": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
+    "vdn_dwconv7": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
+    "vdn_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_size_t, vp]),
+    "vdn_sizeof_gemm_desc": (C.c_size_t, []),
+    "vdn_offsetof_gemm_zeros": (C.c_size_t, []),
+    "vdn_version": (C.c_char_p, []),
+    "vdn_arch_ok": (C.c_int, []),
+}
+
+for _name, (_res, _args) in EXPORTS.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the library is stale: rebuild
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.vdn_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.vdn_offsetof_gemm_zeros() != GemmDesc.zeros.offset:
+    raise ImportError("vdn_gemm_desc layout mismatch between include/vdn.h and vdn/_abi.py — rebuild the library")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        if rc <= -1000:
+            raise VdnError(f"{what}: HIP error {-rc - 1000}")
+        raise VdnError(f"{what}: rejected arguments (vdn_status {rc})")

@@ -1,0 +1,126 @@
+"""Drop-in for depth_anything_v2/depth_anything_v2.py:12-92 — same class name, constructor, methods and
+state-dict keys; the forward pass runs on libvdn_hip.so (MI355X), never on torch ops."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import modules, util
+from .engine import DPTEngine, EncoderEngine, MemoryEngine
+from .runtime import Runtime
+
+_MEAN = (0.485, 0.456, 0.406)
+_STD = (0.229, 0.224, 0.225)
+
+
+def _half_dtype():
+    return torch.bfloat16 if os.environ.get("VDN_HALF", "f16").lower() in ("bf16", "bfloat16") else torch.float16
+
+
+class _EngineOwner(nn.Module):
+    """Shared plumbing: engines are (re)built lazily from the current parameters and device."""
+
+    def __init__(self):
+        super().__init__()
+        self._eng = None
+
+    def _apply(self, fn, *a, **k):
+        self._eng = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._eng = None
+        return super().load_state_dict(*a, **k)
+
+    def _runtime(self) -> Runtime:
+        dev = next(self.parameters()).device
+        return Runtime(dev, _half_dtype())
+
+    @staticmethod
+    def preprocess(rt: Runtime, frames_rgb01: torch.Tensor, input_size: int) -> torch.Tensor:
+        """[n,h,w,3] f32 RGB in [0,1] on device -> f32 [n,3,H,W]: Resize(lower_bound, multiple of 14,
+        cubic) + NormalizeImage + PrepareForNet (util/transform.py:109-148). The cubic kernel is the
+        A=-0.75 half-pixel one cv2.INTER_CUBIC uses; cv2 itself is absent offline so this step is
+        parity-unpinned."""
+        n, h, w, _ = frames_rgb01.shape
+        nw, nh = util.get_size(w, h, input_size)
+        mean = torch.tensor(_MEAN, device=rt.device)
+        std = torch.tensor(_STD, device=rt.device)
+        if (nh, nw) == (h, w):
+            res = frames_rgb01
+        else:
+            res = torch.empty((n, nh, nw, 3), dtype=torch.float32, device=rt.device)
+            src = frames_rgb01.contiguous()
+            for i in range(n):
+                rt.bicubic(src[i], res[i], h, w, nh, nw, 3, nh / h, nw / w)
+        return ((res - mean) / std).permute(0, 3, 1, 2).contiguous()
+
+
+class DepthAnythingV2(_EngineOwner):
+    def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False,
+                 use_clstoken=False, max_memory_length=6):
+        super().__init__()
+        if use_bn or use_clstoken:
+            raise NotImplementedError("use_bn / use_clstoken are never enabled by the reference configs (run_video.py:28-33)")
+        self.intermediate_layer_idx = {k: v["taps"] for k, v in modules.ENCODERS.items()}
+        self.encoder = encoder
+        cfg = modules.ENCODERS[encoder]
+        self.max_memory_length = max_memory_length
+        self.pretrained = modules.dinov2(encoder)
+        self.memory_block = modules.memory_block(cfg["dim"], max_memory_length, 4)
+        self.depth_head = modules.dpt_head(cfg["dim"], features, out_channels)
+        self._features, self._out_channels = features, list(out_channels)
+
+    def _engines(self):
+        if self._eng is None:
+            rt = self._runtime()
+            cfg = modules.ENCODERS[self.encoder]
+            self._eng = dict(
+                rt=rt, enc=EncoderEngine(rt, self.pretrained, cfg),
+                mem=MemoryEngine(rt, self.memory_block, cfg["dim"], self.max_memory_length),
+                head=DPTEngine(rt, self.depth_head, cfg["dim"], self._features, self._out_channels, temporal=False))
+        return self._eng
+
+    def clear_memory(self):
+        if self._eng is not None:
+            self._eng["mem"].clear()
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, _pre_relu: bool = False) -> torch.Tensor:
+        """x f32 [B,3,H,W] (H,W multiples of 14, square) -> f32 [B,H,W]; mutates the memory bank
+        (depth_anything_v2.py:45-55). `_pre_relu` (tests only) returns the signed map before the
+        final ReLUs; the memory update always sees the ReLU'd depth as in the reference."""
+        e = self._engines()
+        rt, enc, mem, head = e["rt"], e["enc"], e["mem"], e["head"]
+        x = x.to(device=rt.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        taps, last_f32, (ph, pw) = enc.run(x, want_f32_last=True)
+        fm = mem.forward(last_f32, B, ph * pw)
+        depth = head.run([taps[0], taps[1], taps[2], fm], B, ph, pw, relu=not _pre_relu)
+        out = depth.clone()
+        if _pre_relu:
+            depth.clamp_(min=0)
+        mem.update(fm, depth, B, ph, pw)
+        return out
+
+    @torch.no_grad()
+    def infer_image(self, raw_image: np.ndarray, input_size: int = 518) -> np.ndarray:
+        """BGR u8 [h,w,3] -> f32 [h,w] (depth_anything_v2.py:57-65)."""
+        image, (h, w) = self.image2tensor(raw_image, input_size)
+        depth = self.forward(image)
+        rt = self._engines()["rt"]
+        if tuple(depth.shape[-2:]) != (h, w):
+            out = torch.empty((1, h, w), dtype=torch.float32, device=rt.device)
+            rt.upsample_f32(depth.contiguous(), out, 1, depth.shape[-2], depth.shape[-1], h, w)
+            depth = out
+        return depth[0].cpu().numpy()
+
+    def image2tensor(self, raw_image: np.ndarray, input_size: int = 518):
+        """depth_anything_v2.py:67-92."""
+        rt = self._engines()["rt"]
+        h, w = raw_image.shape[:2]
+        img = torch.from_numpy(np.ascontiguousarray(raw_image[:, :, ::-1])).to(rt.device).float() / 255.0
+        return self.preprocess(rt, img[None], input_size), (h, w)

@@ -1,0 +1,435 @@
+"""Executors: the reference's forward passes as sequences of libvdn_hip.so launches.
+
+Data layout in HBM (everything channels-last, resident for the whole forward):
+  residual streams (ViT tokens, memory-attention state, temporal hidden state)  f32 [rows, C]
+  GEMM operands / activations between convs                                      half [rows, C]
+  attention operands   Q,K  half [B*heads, tpad, 64];  V^T half [B*heads, 64, tpad]
+  memory bank          per layer ring of projected+rotated K / V^T (6 slots), written once per frame
+Every function cites the reference code it stands for (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _abi as abi
+from . import pack
+from .runtime import Runtime, ceil_to
+
+GELU, RELU = abi.ACT_GELU, abi.ACT_RELU
+PATCH = 14
+
+
+# =============================================================================================
+class EncoderEngine:
+    """DINOv2 ViT: depth_anything_v2/dinov2.py:212-231,271-321 + dinov2_layers/{block,attention,mlp}.py."""
+
+    def __init__(self, rt: Runtime, mod, cfg: dict):
+        self.rt, self.cfg = rt, cfg
+        self.C, self.heads, self.depth, self.taps = cfg["dim"], cfg["heads"], cfg["depth"], cfg["taps"]
+        h = rt.half
+        self.w_patch = pack.patch_embed(mod.patch_embed.proj.weight, h)
+        self.b_patch = pack.f32(mod.patch_embed.proj.bias)
+        self.cls = pack.f32(mod.cls_token).reshape(-1)
+        self.pos = pack.f32(mod.pos_embed).reshape(-1, self.C)  # [1+37*37, C]
+        self.blocks = []
+        for b in mod.blocks:
+            self.blocks.append(dict(
+                n1w=pack.f32(b.norm1.weight), n1b=pack.f32(b.norm1.bias),
+                wqkv=pack.linear(b.attn.qkv.weight, h), bqkv=pack.f32(b.attn.qkv.bias),
+                wproj=pack.linear(b.attn.proj.weight, h), bproj=pack.f32(b.attn.proj.bias),
+                ls1=pack.f32(b.ls1.gamma),
+                n2w=pack.f32(b.norm2.weight), n2b=pack.f32(b.norm2.bias),
+                wfc1=pack.linear(b.mlp.fc1.weight, h), bfc1=pack.f32(b.mlp.fc1.bias),
+                wfc2=pack.linear(b.mlp.fc2.weight, h), bfc2=pack.f32(b.mlp.fc2.bias),
+                ls2=pack.f32(b.ls2.gamma)))
+        self.nw, self.nb = pack.f32(mod.norm.weight), pack.f32(mod.norm.bias)
+        self._pos_cache = {}
+
+    def _pos_for(self, ph: int, pw: int):
+        """interpolate_pos_encoding (dinov2.py:179-210): identity for the square 37x37 grid, else bicubic
+        resample with scale ((ph+0.1)/37, (pw+0.1)/37). Returns (f32 [1+P, C] table, f32 [C] cls row)."""
+        key = (ph, pw)
+        if key not in self._pos_cache:
+            rt, C = self.rt, self.C
+            gs = int(math.sqrt(self.pos.shape[0] - 1))
+            if ph * pw == gs * gs and ph == pw:
+                table = self.pos
+            else:
+                table = torch.empty((1 + ph * pw, C), dtype=torch.float32, device=rt.device)
+                table[0].copy_(self.pos[0])
+                sx, sy = float(ph + 0.1) / gs, float(pw + 0.1) / gs
+                rt.bicubic(self.pos[1:], table[1:], gs, gs, ph, pw, C, sx, sy)
+            self._pos_cache[key] = (table, (self.cls + table[0]).contiguous())
+        return self._pos_cache[key]
+
+    def run(self, x: torch.Tensor, want_f32_last: bool = False):
+        """x f32 [Bf,3,H,W] -> 4 final-normed patch-token maps, half [Bf*P, C] each (cls dropped,
+        dinov2.py:309-312); optionally also the last one in f32 (input of the memory block)."""
+        rt, C, Hh = self.rt, self.C, self.heads
+        Bf, _, H, W = x.shape
+        assert H % PATCH == 0 and W % PATCH == 0, "input sides must be multiples of 14 (patch_embed.py:73-74)"
+        ph, pw = H // PATCH, W // PATCH
+        P, N = ph * pw, ph * pw + 1
+        M = Bf * N
+        table, cls_row = self._pos_for(ph, pw)
+        rows = rt.hbuf("patch_rows", (Bf * P, 640))
+        rt.patchify(x, rows, Bf, H, W, 640)
+        tok = rt.fbuf("tokens", (M, C))
+        rt.fill_row(tok, cls_row, Bf, N, 0, C)
+        rt.gemm(rows, self.w_patch, Bf * P, C, 640, out=tok, bias=self.b_patch, tab=table, tab_mod=P, tab_off=1,
+                row_group=P, row_skip=1)
+        npad = ceil_to(N, 64)
+        q = rt.hbuf("enc_q", (Bf * Hh, npad, 64), zero=True)
+        k = rt.hbuf("enc_k", (Bf * Hh, npad, 64), zero=True)
+        vt = rt.hbuf("enc_vt", (Bf * Hh, 64, npad), zero=True)
+        hn = rt.hbuf("enc_ln", (M, C))
+        att = rt.hbuf("enc_att", (M, C))
+        f1 = rt.hbuf("enc_fc1", (M, 4 * C))
+        heads = dict(dst=[q, k, vt], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
+        outs, last_f32 = [], None
+        for i, b in enumerate(self.blocks):
+            rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
+            rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads)
+            rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5)
+            rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok)
+            rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
+            rt.gemm(hn, b["wfc1"], M, 4 * C, C, bias=b["bfc1"], act=GELU, out=f1)
+            rt.gemm(f1, b["wfc2"], M, C, 4 * C, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok)
+            if i in self.taps:
+                j = self.taps.index(i)
+                t = rt.hbuf(f"tap{j}", (Bf * P, C))
+                f = None
+                if want_f32_last and j == len(self.taps) - 1:
+                    f = last_f32 = rt.fbuf("tap_last_f32", (Bf * P, C))
+                rt.layernorm(tok, M, C, self.nw, self.nb, 1e-6, out_h=t, out_f=f, out_group=N)
+                outs.append(t)
+        return outs, last_f32, (ph, pw)
+
+
+# =============================================================================================
+class TemporalEngine:
+    """TemporalModule: video_depth_anything/motion_module/motion_module.py:102-136,174-192,245-326,
+    attention.py:182-211 (softmax attention over frames), :296-384 (GEGLU feed-forward)."""
+
+    def __init__(self, rt: Runtime, mod, c: int, idx: int):
+        self.rt, self.c, self.idx = rt, c, idx
+        h = rt.half
+        tt = mod.temporal_transformer
+        blk = tt.transformer_blocks[0]
+        self.gnw, self.gnb = pack.f32(tt.norm.weight), pack.f32(tt.norm.bias)
+        self.w_in, self.b_in = pack.linear(tt.proj_in.weight, h), pack.f32(tt.proj_in.bias)
+        self.att = []
+        for i in range(2):
+            a = blk.attention_blocks[i]
+            wqkv, _ = pack.cat_proj([a.to_q.weight, a.to_k.weight, a.to_v.weight], [None, None, None], [0, 0, 0], h)
+            self.att.append(dict(
+                nw=pack.f32(blk.norms[i].weight), nb=pack.f32(blk.norms[i].bias), wqkv=wqkv,
+                pe=pack.f32(a.pos_encoder.pe).reshape(-1, c),
+                wo=pack.linear(a.to_out[0].weight, h), bo=pack.f32(a.to_out[0].bias)))
+        self.fnw, self.fnb = pack.f32(blk.ff_norm.weight), pack.f32(blk.ff_norm.bias)
+        self.wg, self.bg = pack.geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, h)
+        self.wf2, self.bf2 = pack.linear(blk.ff.net[2].weight, h), pack.f32(blk.ff.net[2].bias)
+        self.w_out, self.b_out = pack.linear(tt.proj_out.weight, h), pack.f32(tt.proj_out.bias)
+
+    def run(self, x: torch.Tensor, B: int, T: int, HW: int) -> torch.Tensor:
+        """x half [(b f) * HW, c] (NHWC frames) -> same shape."""
+        rt, c = self.rt, self.c
+        M = B * T * HW
+        assert T <= self.att[0]["pe"].shape[0], "clip longer than temporal_max_len (motion_module.py:200-213)"
+        g = rt.hbuf("tm_gn", (M, c))
+        rt.groupnorm(x, g, B * T, HW, c, 32, self.gnw, self.gnb, 1e-6)
+        hs = rt.fbuf("tm_h", (M, c))
+        rt.gemm(g, self.w_in, M, c, c, bias=self.b_in, out=hs)
+        n = rt.hbuf("tm_n", (M, c))
+        qkv = rt.hbuf("tm_qkv", (M, 3 * c))
+        a = rt.hbuf("tm_a", (M, c))
+        for at in self.att:
+            rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n, addtab=at["pe"], tab_div=HW, tab_mod=T)
+            rt.gemm(n, at["wqkv"], M, 3 * c, c, out=qkv)
+            rt.temporal_attn(qkv, a, B, T, HW, c, 8, (c // 8) ** -0.5)
+            rt.gemm(a, at["wo"], M, c, c, bias=at["bo"], res1=hs, out=hs)
+        rt.layernorm(hs, M, c, self.fnw, self.fnb, 1e-5, out_h=n)
+        gg = rt.hbuf("tm_gg", (M, 4 * c))
+        rt.gemm(n, self.wg, M, 8 * c, c, bias=self.bg, store=abi.ST_GEGLU, out=gg)
+        hh = rt.hbuf("tm_hh", (M, c))
+        rt.gemm(gg, self.wf2, M, c, 4 * c, bias=self.bf2, res1=hs, out=hh)
+        y = rt.hbuf(f"tm_out{self.idx}", (M, c))
+        rt.gemm(hh, self.w_out, M, c, c, bias=self.b_out, res1=x, out=y)
+        return y
+
+
+# =============================================================================================
+class DPTEngine:
+    """DPTHead / DPTHeadTemporal: depth_anything_v2/dpt.py:116-151, util/blocks.py:57-148,
+    video_depth_anything/dpt_temporal.py:53-127."""
+
+    def __init__(self, rt: Runtime, mod, in_ch: int, features: int, out_channels, temporal: bool):
+        self.rt, self.C, self.F, self.oc = rt, in_ch, features, list(out_channels)
+        h = rt.half
+        self.proj = [(pack.conv1x1(p.weight, h), pack.f32(p.bias)) for p in mod.projects]
+        self.rt0 = pack.conv_transpose(mod.resize_layers[0].weight, mod.resize_layers[0].bias, h)
+        self.rt1 = pack.conv_transpose(mod.resize_layers[1].weight, mod.resize_layers[1].bias, h)
+        self.rs3 = (pack.conv3x3(mod.resize_layers[3].weight, h), pack.f32(mod.resize_layers[3].bias))
+        s = mod.scratch
+        self.rn = [pack.conv3x3(getattr(s, f"layer{i + 1}_rn").weight, h) for i in range(4)]
+
+        def rcu(r):
+            return dict(w1=pack.conv3x3(r.conv1.weight, h), b1=pack.f32(r.conv1.bias),
+                        w2=pack.conv3x3(r.conv2.weight, h), b2=pack.f32(r.conv2.bias))
+
+        self.ref = {}
+        for i in range(1, 5):
+            f = getattr(s, f"refinenet{i}")
+            self.ref[i] = dict(r1=rcu(f.resConfUnit1), r2=rcu(f.resConfUnit2),
+                               wo=pack.conv1x1(f.out_conv.weight, h), bo=pack.f32(f.out_conv.bias))
+        self.oc1 = (pack.conv3x3(s.output_conv1.weight, h), pack.f32(s.output_conv1.bias))
+        self.oc2 = (pack.conv3x3(s.output_conv2[0].weight, h), pack.f32(s.output_conv2[0].bias))
+        self.w_last = pack.f32(s.output_conv2[2].weight).reshape(-1)
+        self.b_last = float(s.output_conv2[2].bias.detach().float().item())
+        self.temporal = None
+        if temporal:
+            chans = [self.oc[2], self.oc[3], features, features]
+            self.temporal = [TemporalEngine(rt, mod.motion_modules[i], chans[i], i) for i in range(4)]
+
+    # -- helpers
+    def _conv3(self, x, w, Bf, H, W, Cin, Cout, name, *, stride=1, bias=None, relu_a=False, act=0, res1=None, res2=None):
+        OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        out = self.rt.hbuf(name, (Bf * OH * OW, Cout))
+        self.rt.gemm(x, w, Bf * OH * OW, Cout, 9 * Cin, out=out, bias=bias, act=act, relu_a=relu_a, res1=res1, res2=res2,
+                     conv=dict(B=Bf, H=H, W=W, C=Cin, OH=OH, OW=OW, stride=stride))
+        return out
+
+    def _rcu(self, r, x, Bf, H, W, name, extra=None):
+        """ResidualConvUnit (blocks.py:67-80): conv2(relu(conv1(relu(x)))) + x [+ extra]."""
+        F = self.F
+        t = self._conv3(x, r["w1"], Bf, H, W, F, F, "rcu_t", bias=r["b1"], relu_a=True, act=RELU)
+        return self._conv3(t, r["w2"], Bf, H, W, F, F, name, bias=r["b2"], res1=x, res2=extra)
+
+    def _fusion(self, i, Bf, size_in, size_out, prev, skip=None):
+        """FeatureFusionBlock (blocks.py:123-148). The 1x1 out_conv commutes with the bilinear resize
+        (both linear, interpolation weights sum to 1), so it runs at the LOW resolution: 4x fewer
+        flops, same result up to rounding."""
+        rt, F = self.rt, self.F
+        H, W = size_in
+        f = self.ref[i]
+        x = prev
+        if skip is not None:
+            x = self._rcu(f["r1"], skip, Bf, H, W, f"ff{i}_s", extra=prev)
+        u = self._rcu(f["r2"], x, Bf, H, W, f"ff{i}_u")
+        v = rt.hbuf(f"ff{i}_v", (Bf * H * W, F))
+        rt.gemm(u, f["wo"], Bf * H * W, F, F, bias=f["bo"], out=v)
+        OH, OW = size_out
+        p = rt.hbuf(f"path{i}", (Bf * OH * OW, F))
+        rt.upsample(v, p, Bf, H, W, OH, OW, F)
+        return p
+
+    def run(self, taps: List[torch.Tensor], Bf: int, ph: int, pw: int, T: Optional[int] = None, relu: bool = True):
+        rt, C, F, oc = self.rt, self.C, self.F, self.oc
+        P = ph * pw
+        pr = []
+        for i in range(4):
+            o = rt.hbuf(f"proj{i}", (Bf * P, oc[i]))
+            rt.gemm(taps[i], self.proj[i][0], Bf * P, oc[i], C, bias=self.proj[i][1], out=o)
+            pr.append(o)
+        s1, s2, s3 = (4 * ph, 4 * pw), (2 * ph, 2 * pw), (ph, pw)
+        s4 = ((ph + 2 - 3) // 2 + 1, (pw + 2 - 3) // 2 + 1)
+        l1 = rt.hbuf("l1", (Bf * s1[0] * s1[1], oc[0]))
+        rt.gemm(pr[0], self.rt0[0], Bf * P, 16 * oc[0], oc[0], bias=self.rt0[1], store=abi.ST_CONVT, out=l1,
+                convt=dict(k=4, cout=oc[0], B=Bf, H=ph, W=pw))
+        l2 = rt.hbuf("l2", (Bf * s2[0] * s2[1], oc[1]))
+        rt.gemm(pr[1], self.rt1[0], Bf * P, 4 * oc[1], oc[1], bias=self.rt1[1], store=abi.ST_CONVT, out=l2,
+                convt=dict(k=2, cout=oc[1], B=Bf, H=ph, W=pw))
+        l3 = pr[2]
+        l4 = self._conv3(pr[3], self.rs3[0], Bf, ph, pw, oc[3], oc[3], "l4", stride=2, bias=self.rs3[1])
+        if self.temporal is not None:
+            B = Bf // T
+            l3 = self.temporal[0].run(l3, B, T, s3[0] * s3[1])
+            l4 = self.temporal[1].run(l4, B, T, s4[0] * s4[1])
+        r1 = self._conv3(l1, self.rn[0], Bf, s1[0], s1[1], oc[0], F, "l1_rn")
+        r2 = self._conv3(l2, self.rn[1], Bf, s2[0], s2[1], oc[1], F, "l2_rn")
+        r3 = self._conv3(l3, self.rn[2], Bf, s3[0], s3[1], oc[2], F, "l3_rn")
+        r4 = self._conv3(l4, self.rn[3], Bf, s4[0], s4[1], oc[3], F, "l4_rn")
+        p4 = self._fusion(4, Bf, s4, s3, r4)
+        if self.temporal is not None:
+            p4 = self.temporal[2].run(p4, Bf // T, T, s3[0] * s3[1])
+        p3 = self._fusion(3, Bf, s3, s2, p4, r3)
+        if self.temporal is not None:
+            p3 = self.temporal[3].run(p3, Bf // T, T, s2[0] * s2[1])
+        p2 = self._fusion(2, Bf, s2, s1, p3, r2)
+        s0 = (2 * s1[0], 2 * s1[1])
+        p1 = self._fusion(1, Bf, s1, s0, p2, r1)
+        o1 = self._conv3(p1, self.oc1[0], Bf, s0[0], s0[1], F, F // 2, "out1", bias=self.oc1[1])
+        H, W = ph * PATCH, pw * PATCH
+        up = rt.hbuf("out_up", (Bf * H * W, F // 2))
+        rt.upsample(o1, up, Bf, s0[0], s0[1], H, W, F // 2)
+        o2 = self._conv3(up, self.oc2[0], Bf, H, W, F // 2, 32, "out2", bias=self.oc2[1], act=RELU)
+        depth = rt.fbuf("depth", (Bf, H, W))
+        rt.head_out(o2, self.w_last, self.b_last, depth, Bf * H * W, 32, relu)
+        return depth
+
+
+# =============================================================================================
+class MemoryEngine:
+    """MemoryBlock: depth_anything_v2/memory_block.py:83-125 over sam2/modeling/{memory_attention.py:58-169,
+    sam/transformer.py:275-311, position_encoding.py:192-239, memory_encoder.py:158-181}.
+
+    MI355X-first differences that leave the result unchanged:
+      * the reference re-projects all S stored frames through k_proj/v_proj of every layer on every
+        call; here each pushed frame's rotated K and V^T are written once into a per-layer 6-slot
+        ring in HBM (keys are order-invariant under softmax, RoPE depends on t % P only), so the
+        cross-attention reads them in place;
+      * memory_pos_enc / maskmem_tpos_enc never reach the output under the flags MemoryBlock sets
+        (pos_enc_at_cross_attn_keys=False, memory_block.py:39), so they are not computed.
+    """
+
+    def __init__(self, rt: Runtime, mod, C: int, max_len: int):
+        self.rt, self.C, self.heads, self.max_len = rt, C, C // 64, max_len
+        h = rt.half
+        ma = mod.memory_attention
+        self.layers = []
+        for l in ma.layers:
+            sa, ca = l.self_attn, l.cross_attn_image
+            wqkv, bqkv = pack.cat_proj([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight],
+                                       [sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias], [1, 1, 0], h)
+            wq, bq = pack.cat_proj([ca.q_proj.weight], [ca.q_proj.bias], [1], h)
+            wkv, bkv = pack.cat_proj([ca.k_proj.weight, ca.v_proj.weight], [ca.k_proj.bias, ca.v_proj.bias], [1, 0], h)
+            self.layers.append(dict(
+                n1w=pack.f32(l.norm1.weight), n1b=pack.f32(l.norm1.bias),
+                n2w=pack.f32(l.norm2.weight), n2b=pack.f32(l.norm2.bias),
+                n3w=pack.f32(l.norm3.weight), n3b=pack.f32(l.norm3.bias),
+                wqkv=wqkv, bqkv=bqkv, wso=pack.linear(sa.out_proj.weight, h), bso=pack.f32(sa.out_proj.bias),
+                wq=wq, bq=bq, wkv=wkv, bkv=bkv, wco=pack.linear(ca.out_proj.weight, h), bco=pack.f32(ca.out_proj.bias),
+                w1=pack.linear(l.linear1.weight, h), b1=pack.f32(l.linear1.bias),
+                w2=pack.linear(l.linear2.weight, h), b2=pack.f32(l.linear2.bias)))
+        self.nw, self.nb = pack.f32(ma.norm.weight), pack.f32(ma.norm.bias)
+        self.curr_pos = pack.f32(mod.curr_pos_enc).reshape(-1)
+        self.no_mem = mod.no_mem_embed.detach().reshape(1, -1).to(h)
+        me = mod.memory_encoder
+
+        def flat(*ts):
+            return torch.cat([t.detach().float().reshape(-1) for t in ts]).contiguous()
+
+        e0, e1 = me.mask_downsampler[0].encoder, me.mask_downsampler[1].encoder
+        self.md1 = flat(e0[0].weight, e0[0].bias, e0[1].weight, e0[1].bias, e0[3].weight, e0[3].bias)
+        self.md2 = flat(e1[0].weight, e1[0].bias, e1[1].weight, e1[1].bias, e1[3].weight, e1[3].bias)
+        assert self.md1.numel() == 53 and self.md2.numel() == 2598
+        self.wpix, self.bpix = pack.conv1x1(me.pix_feat_proj.weight, h), pack.f32(me.pix_feat_proj.bias)
+        self.cx = []
+        for b in me.fuser.layers:
+            self.cx.append(dict(
+                wdw=b.dwconv.weight.detach().float().reshape(C, 49).t().contiguous(), bdw=pack.f32(b.dwconv.bias),
+                nw=pack.f32(b.norm.weight), nb=pack.f32(b.norm.bias),
+                w1=pack.linear(b.pwconv1.weight, h), b1=pack.f32(b.pwconv1.bias),
+                w2=pack.linear(b.pwconv2.weight, h), b2=pack.f32(b.pwconv2.bias), g=pack.f32(b.gamma)))
+        self.count = 0
+        self._shape = None
+        self._rope = {}
+        self._nomem_ready = None
+
+    def clear(self):
+        self.count = 0
+        self._shape = None
+
+    @property
+    def S(self):
+        return min(self.count, self.max_len)
+
+    def _rope_for(self, side):
+        if side not in self._rope:
+            self._rope[side] = pack.rope_table(side, side, 64, device=self.rt.device)
+        return self._rope[side]
+
+    def _bank(self, B, P):
+        rt, Hh = self.rt, self.heads
+        tp = ceil_to(self.max_len * P, 64)
+        ks = [rt.hbuf(f"mem_k{l}", (B * Hh, tp, 64), zero=True) for l in range(len(self.layers))]
+        vs = [rt.hbuf(f"mem_vt{l}", (B * Hh, 64, tp), zero=True) for l in range(len(self.layers))]
+        return ks, vs, tp
+
+    def forward(self, feat_f32: torch.Tensor, B: int, P: int) -> torch.Tensor:
+        """feat_f32 [B*P, C] (final-normed tap 4) -> half [B*P, C] (memory_block.py:92-125)."""
+        rt, C, Hh = self.rt, self.C, self.heads
+        if self._shape != (B, P):
+            self._shape, self.count = (B, P), 0
+        side = int(math.sqrt(P))
+        assert side * side == P, "MemoryBlock assumes square inputs (memory_block.py:85)"
+        M = B * P
+        cs = self._rope_for(side)
+        pp = ceil_to(P, 64)
+        x = rt.fbuf("ma_x", (M, C))
+        rt.add_vec(feat_f32, self.curr_pos, 0.1, x, M, C)  # memory_attention.py:140-141
+        n = rt.hbuf("ma_n", (M, C))
+        q = rt.hbuf("ma_q", (B * Hh, pp, 64), zero=True)
+        k = rt.hbuf("ma_k", (B * Hh, pp, 64), zero=True)
+        vt = rt.hbuf("ma_vt", (B * Hh, 64, pp), zero=True)
+        att = rt.hbuf("ma_att", (M, C))
+        h2 = rt.hbuf("ma_h2", (M, 2 * C))
+        ks, vs, tp = self._bank(B, P)
+        S = self.S
+        if S == 0:
+            # empty bank: keys/values come from no_mem_embed broadcast to P tokens (memory_block.py:115-123)
+            nk, nk_pad = P, pp
+            a_nm = rt.hbuf("ma_nomem_a", (M, C))
+            a_nm.copy_(self.no_mem.expand(M, C))
+            ks = [rt.hbuf(f"nomem_k{l}", (B * Hh, pp, 64), zero=True) for l in range(len(self.layers))]
+            vs = [rt.hbuf(f"nomem_vt{l}", (B * Hh, 64, pp), zero=True) for l in range(len(self.layers))]
+            for l, L in enumerate(self.layers):
+                rt.gemm(a_nm, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
+                        heads=dict(dst=[ks[l], vs[l]], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
+                                   tokens=P, tpad=pp))
+        else:
+            nk, nk_pad = S * P, tp
+        sh = dict(dst=[q, k, vt], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
+        qh = dict(dst=[q], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
+        for l, L in enumerate(self.layers):
+            rt.layernorm(x, M, C, L["n1w"], L["n1b"], 1e-5, out_h=n)
+            rt.gemm(n, L["wqkv"], M, 3 * C, C, bias=L["bqkv"], store=abi.ST_HEADS, heads=sh)
+            rt.flash_attn(q, k, vt, att, B, Hh, P, pp, P, pp, 0.125)
+            rt.gemm(att, L["wso"], M, C, C, bias=L["bso"], res1=x, out=x)
+            rt.layernorm(x, M, C, L["n2w"], L["n2b"], 1e-5, out_h=n, addvec=self.curr_pos, alpha=1.0)
+            rt.gemm(n, L["wq"], M, C, C, bias=L["bq"], store=abi.ST_HEADS, heads=qh)
+            rt.flash_attn(q, ks[l], vs[l], att, B, Hh, P, pp, nk, nk_pad, 0.125)
+            rt.gemm(att, L["wco"], M, C, C, bias=L["bco"], res1=x, out=x)
+            rt.layernorm(x, M, C, L["n3w"], L["n3b"], 1e-5, out_h=n)
+            rt.gemm(n, L["w1"], M, 2 * C, C, bias=L["b1"], act=GELU, out=h2)
+            rt.gemm(h2, L["w2"], M, C, 2 * C, bias=L["b2"], res1=x, out=x)
+        out = rt.hbuf("mem_out", (M, C))
+        rt.layernorm(x, M, C, self.nw, self.nb, 1e-5, out_h=out)
+        return out
+
+    def update(self, mem_out: torch.Tensor, depth: torch.Tensor, B: int, ph: int, pw: int):
+        """update_memory (memory_block.py:83-90): MemoryEncoder then push; here the push writes the
+        frame's per-layer rotated K / V^T into ring slot count % max_len."""
+        rt, C, Hh = self.rt, self.C, self.heads
+        P, M = ph * pw, B * ph * pw
+        H, W = depth.shape[-2], depth.shape[-1]
+        h1, w1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        h2, w2 = (h1 - 7) // 7 + 1, (w1 - 7) // 7 + 1
+        assert (h2, w2) == (ph, pw), "mask downsampler output must match the feature grid (memory_encoder.py:173)"
+        m1 = rt.fbuf("me_m1", (B, h1, w1))
+        rt.mask_down1(depth, m1, B, H, W, h1, w1, self.md1)
+        m2 = rt.fbuf("me_m2", (M,))
+        rt.mask_down2(m1, m2, B, h1, w1, h2, w2, self.md2)
+        x = rt.fbuf("me_x", (M, C))
+        rt.gemm(mem_out, self.wpix, M, C, C, bias=self.bpix, rowadd=m2, out=x)
+        d = rt.fbuf("me_dw", (M, C))
+        n = rt.hbuf("me_n", (M, C))
+        h4 = rt.hbuf("me_h4", (M, 4 * C))
+        feat = rt.hbuf("mem_feat", (M, C))
+        for j, cx in enumerate(self.cx):
+            rt.dwconv7(x, d, B, ph, pw, C, cx["wdw"], cx["bdw"])
+            rt.layernorm(d, M, C, cx["nw"], cx["nb"], 1e-6, out_h=n)
+            rt.gemm(n, cx["w1"], M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4)
+            rt.gemm(h4, cx["w2"], M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=(x if j == 0 else feat))
+        ks, vs, tp = self._bank(B, P)
+        slot = self.count % self.max_len
+        cs = self._rope_for(int(math.sqrt(P)))
+        for l, L in enumerate(self.layers):
+            rt.gemm(feat, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
+                    heads=dict(dst=[ks[l], vs[l]], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
+                               tokens=P, tok_off=slot * P, tpad=tp))
+        self.count += 1
+        return feat

@@ -1,0 +1,205 @@
+"""Device runtime: workspace arena, launch recording, and tensor-level wrappers over the C-ABI.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic op on the path is a launch of
+libvdn_hip.so. Launches go to torch's current stream, so the caller's stream semantics (and
+torch.cuda.CUDAGraph capture) apply unchanged.
+
+Recording: with `rt.record(key)` every launch is also appended to a plan; `rt.replay(key)` re-issues
+the same ctypes calls without re-deriving shapes or descriptors (workspace pointers are stable
+because buffers come from the arena by name).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from contextlib import contextmanager
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _abi as abi
+from ._abi import F16, BF16, F32
+
+_TDT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
+
+
+def ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Runtime:
+    def __init__(self, device: torch.device, half: torch.dtype = torch.float16):
+        if device.type != "cuda":
+            raise abi.VdnError("vdn kernels run on an MI355X ('cuda' device under ROCm); there is no CPU path")
+        self.device = device
+        self.half = half
+        self.dt = _TDT[half]
+        self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._plans: Dict[object, list] = {}
+        self._rec: Optional[list] = None
+        self._keep: List[object] = []
+
+    # ------------------------------------------------------------------ memory
+    def buf(self, name: str, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def hbuf(self, name, shape, zero=False):
+        return self.buf(name, shape, self.half, zero)
+
+    def fbuf(self, name, shape, zero=False):
+        return self.buf(name, shape, torch.float32, zero)
+
+    def workspace_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+    # ------------------------------------------------------------------ launch / record / replay
+    def _launch(self, fn, *args):
+        rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
+        abi.check(rc, fn.__name__)
+        if self._rec is not None:
+            self._rec.append((fn, args))
+
+    @contextmanager
+    def record(self, key):
+        self._rec = []
+        try:
+            yield
+            self._plans[key] = self._rec
+        finally:
+            self._rec = None
+
+    def has_plan(self, key) -> bool:
+        return key in self._plans
+
+    def replay(self, key):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        for fn, args in self._plans[key]:
+            rc = fn(*args, s)
+            if rc != 0:
+                abi.check(rc, fn.__name__)
+
+    def drop_plans(self):
+        self._plans.clear()
+
+    # ------------------------------------------------------------------ ops
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return None if t is None else t.data_ptr()
+
+    def gemm(self, A: torch.Tensor, W: torch.Tensor, M: int, N: int, K: int, *, lda: Optional[int] = None,
+             out: Optional[torch.Tensor] = None, ldc: Optional[int] = None, bias=None, act: int = 0, gamma=None,
+             rowadd=None, tab=None, tab_mod: int = 0, tab_off: int = 0, res1=None, ldr1=None, res2=None, ldr2=None,
+             conv: Optional[dict] = None, relu_a: bool = False, store: int = abi.ST_PLAIN, row_group: int = 0,
+             row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None):
+        d = abi.GemmDesc()
+        d.dt = self.dt
+        d.M, d.N, d.K = M, N, K
+        d.A = A.data_ptr()
+        d.relu_a = 1 if relu_a else 0
+        if conv is not None:
+            d.a_mode = abi.A_CONV3X3
+            d.cB, d.cH, d.cW, d.cC = conv["B"], conv["H"], conv["W"], conv["C"]
+            d.cOH, d.cOW, d.cstride = conv["OH"], conv["OW"], conv["stride"]
+            d.lda = conv["C"]
+        else:
+            d.a_mode = abi.A_PLAIN
+            d.lda = lda if lda is not None else K
+        d.W = W.data_ptr()
+        d.ldb = W.shape[1]
+        assert W.shape[0] == N and W.dtype == self.half and A.dtype == self.half, (W.shape, N, W.dtype, A.dtype)
+        d.bias = self._p(bias)
+        d.rowadd = self._p(rowadd)
+        d.act = act
+        d.gamma = self._p(gamma)
+        d.tab = self._p(tab)
+        d.tab_mod, d.tab_off = tab_mod, tab_off
+        if res1 is not None:
+            d.res1, d.res1_dt, d.ldr1 = res1.data_ptr(), _TDT[res1.dtype], (ldr1 if ldr1 is not None else N)
+        if res2 is not None:
+            d.res2, d.res2_dt, d.ldr2 = res2.data_ptr(), _TDT[res2.dtype], (ldr2 if ldr2 is not None else N)
+        d.store = store
+        if out is not None:
+            d.out = out.data_ptr()
+            d.out_dt = _TDT[out.dtype]
+            d.ldc = ldc if ldc is not None else (N // 2 if store == abi.ST_GEGLU else N)
+        d.row_group, d.row_skip = row_group, row_skip
+        if heads is not None:
+            dst = heads["dst"]
+            d.nsplit = len(dst)
+            for i, t in enumerate(dst):
+                d.dst[i] = t.data_ptr()
+                d.transposed[i] = int(heads["transposed"][i])
+                d.rope[i] = int(heads.get("rope", (0, 0, 0))[i])
+            d.heads, d.tokens, d.tok_off, d.tpad = heads["heads"], heads["tokens"], heads.get("tok_off", 0), heads["tpad"]
+            if heads.get("rope_cs") is not None:
+                d.rope_cs, d.rope_mod = heads["rope_cs"].data_ptr(), heads["rope_mod"]
+        if convt is not None:
+            d.ck, d.cout = convt["k"], convt["cout"]
+            d.cB, d.cH, d.cW = convt["B"], convt["H"], convt["W"]
+        d.zeros = self.zeros.data_ptr()
+        self._launch(abi.lib.vdn_gemm, C.byref(d))
+        self._keep_alive(d)
+        return out
+
+    def _keep_alive(self, obj):
+        # descriptors referenced by recorded plans must outlive them
+        if self._rec is not None:
+            self._keep.append(obj)
+
+    def layernorm(self, x: torch.Tensor, rows: int, Cn: int, w, b, eps: float, *, out_h=None, out_f=None, addvec=None,
+                  alpha: float = 1.0, addtab=None, tab_div: int = 1, tab_mod: int = 1, out_group: int = 0):
+        self._launch(abi.lib.vdn_layernorm, x.data_ptr(), _TDT[x.dtype], rows, Cn, w.data_ptr(), b.data_ptr(), eps,
+                     self._p(addvec), alpha, self._p(addtab), tab_div, tab_mod, out_group, self._p(out_h), self.dt,
+                     self._p(out_f))
+
+    def flash_attn(self, Q, K, Vt, out, B: int, H: int, nq: int, nq_pad: int, nk: int, nk_pad: int, scale: float):
+        self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), B, H,
+                     nq, nq_pad, nk, nk_pad, scale)
+
+    def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
+        self._launch(abi.lib.vdn_temporal_attn, self.dt, qkv.data_ptr(), out.data_ptr(), Bv, T, D, c, heads, scale)
+
+    def groupnorm(self, x, y, F: int, HW: int, Cn: int, groups: int, w, b, eps: float):
+        nsplit = 16 if HW >= 1024 else 4
+        part = self.fbuf("gn_partial", (F, nsplit, groups, 2))
+        self._launch(abi.lib.vdn_groupnorm, self.dt, x.data_ptr(), y.data_ptr(), F, HW, Cn, groups, w.data_ptr(),
+                     b.data_ptr(), eps, part.data_ptr(), nsplit)
+
+    def upsample(self, x, y, B: int, IH: int, IW: int, OH: int, OW: int, Cn: int):
+        self._launch(abi.lib.vdn_upsample_bilinear, self.dt, x.data_ptr(), y.data_ptr(), B, IH, IW, OH, OW, Cn)
+
+    def upsample_f32(self, x, y, B: int, IH: int, IW: int, OH: int, OW: int, relu: bool = False):
+        self._launch(abi.lib.vdn_upsample_bilinear_f32, x.data_ptr(), y.data_ptr(), B, IH, IW, OH, OW, int(relu))
+
+    def patchify(self, img, rows, B: int, H: int, W: int, ldk: int):
+        self._launch(abi.lib.vdn_patchify, self.dt, img.data_ptr(), rows.data_ptr(), B, H, W, ldk)
+
+    def fill_row(self, x, vec, B: int, rows_per_b: int, row: int, Cn: int):
+        self._launch(abi.lib.vdn_fill_row, x.data_ptr(), vec.data_ptr(), B, rows_per_b, row, Cn)
+
+    def bicubic(self, src, dst, ih: int, iw: int, oh: int, ow: int, Cn: int, scale_rows: float, scale_cols: float):
+        self._launch(abi.lib.vdn_bicubic, src.data_ptr(), dst.data_ptr(), ih, iw, oh, ow, Cn, scale_rows, scale_cols)
+
+    def add_vec(self, x, vec, alpha: float, y, rows: int, Cn: int):
+        self._launch(abi.lib.vdn_add_vec, x.data_ptr(), vec.data_ptr(), alpha, y.data_ptr(), rows, Cn)
+
+    def head_out(self, feat, w, bias: float, depth, M: int, Cn: int, relu: bool):
+        self._launch(abi.lib.vdn_head_out, self.dt, feat.data_ptr(), w.data_ptr(), bias, depth.data_ptr(), M, Cn,
+                     int(relu))
+
+    def mask_down1(self, depth, out, B, H, W, OH, OW, w):
+        self._launch(abi.lib.vdn_mask_down1, depth.data_ptr(), out.data_ptr(), B, H, W, OH, OW, w.data_ptr())
+
+    def mask_down2(self, x, out, B, H, W, OH, OW, w):
+        self._launch(abi.lib.vdn_mask_down2, x.data_ptr(), out.data_ptr(), B, H, W, OH, OW, w.data_ptr())
+
+    def dwconv7(self, x, y, B, H, W, Cn, w, bias):
+        self._launch(abi.lib.vdn_dwconv7, x.data_ptr(), y.data_ptr(), B, H, W, Cn, w.data_ptr(), bias.data_ptr())
+
+    def cast(self, x, y):
+        self._launch(abi.lib.vdn_cast, x.data_ptr(), _TDT[x.dtype], y.data_ptr(), _TDT[y.dtype], x.numel())

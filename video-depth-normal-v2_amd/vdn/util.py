@@ -1,0 +1,96 @@
+"""Host-side pieces of the drivers (numpy): resize sizing, window table, scale/shift alignment,
+overlap blending. Mirrors utils/util.py and the windowing in video_depth_anything/video_depth.py."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+INFER_LEN = 32
+OVERLAP = 10
+KEYFRAMES = [0, 12, 24, 25, 26, 27, 28, 29, 30, 31]
+INTERP_LEN = 8
+
+
+def get_size(width: int, height: int, target: int = 518, multiple: int = 14) -> Tuple[int, int]:
+    """Resize.get_size (util/transform.py:62-107) for keep_aspect_ratio=True, resize_method='lower_bound'.
+    Returns (new_width, new_height)."""
+    scale_h, scale_w = target / height, target / width
+    if scale_w > scale_h:
+        scale_h = scale_w
+    else:
+        scale_w = scale_h
+
+    def constrain(x: float, min_val: int) -> int:
+        y = int(np.round(x / multiple) * multiple)
+        if y < min_val:
+            y = int(np.ceil(x / multiple) * multiple)
+        return y
+
+    return constrain(scale_w * width, target), constrain(scale_h * height, target)
+
+
+def compute_scale_and_shift(prediction: np.ndarray, target: np.ndarray, mask: np.ndarray):
+    """Closed-form least squares of utils/util.py:40-62 (compute_scale_and_shift_full)."""
+    p = prediction.astype(np.float32)
+    t = target.astype(np.float32)
+    m = mask.astype(np.float32)
+    a00, a01, a11 = np.sum(m * p * p), np.sum(m * p), np.sum(m)
+    b0, b1 = np.sum(m * p * t), np.sum(m * t)
+    det = a00 * a11 - a01 * a01
+    if det == 0:
+        return 1, 0
+    return (a11 * b0 - a01 * b1) / det, (-a01 * b0 + a00 * b1) / det
+
+
+def get_interpolate_frames(pre: List[np.ndarray], post: List[np.ndarray]) -> List[np.ndarray]:
+    """Linear cross-fade of utils/util.py:65-73 (weights 0, 1/(n-1), ..., 1 on the new window)."""
+    assert len(pre) == len(post)
+    n = len(pre)
+    step = 1.0 / (n - 1)
+    w = [0.0] + [i * step for i in range(1, n - 1)] + [1.0]
+    return [pre[i] * (1 - w[i]) + post[i] * w[i] for i in range(n)]
+
+
+def window_table(n_frames: int) -> List[List[int]]:
+    """Frame index feeding every slot of every 32-frame window (video_depth.py:88-102). The
+    overlap copy acts on INPUT tensors only, so the table is known up front and windows are
+    independent work units — this is what the multi-GPU sharding uses."""
+    step = INFER_LEN - OVERLAP
+    pad = (step - (n_frames % step)) % step + (INFER_LEN - step)
+    padded = list(range(n_frames)) + [n_frames - 1] * pad
+    table, prev = [], None
+    for start in range(0, n_frames, step):
+        cur = [padded[start + i] for i in range(INFER_LEN)]
+        if prev is not None:
+            for i, kf in enumerate(KEYFRAMES):
+                cur[i] = prev[kf]
+        table.append(cur)
+        prev = cur
+    return table
+
+
+def stitch(depth_list: List[np.ndarray], org_len: int) -> np.ndarray:
+    """Affine-align each window to the running result and blend the 8 overlap frames
+    (video_depth.py:118-156)."""
+    out: List[np.ndarray] = []
+    ref: List[np.ndarray] = []
+    align_len = OVERLAP - INTERP_LEN
+    kfs = KEYFRAMES[:align_len]
+    for base in range(0, len(depth_list), INFER_LEN):
+        if not out:
+            out.extend(depth_list[:INFER_LEN])
+            ref = [depth_list[base + k] for k in kfs]
+            continue
+        cur = [depth_list[base + i] for i in range(len(kfs))]
+        scale, shift = compute_scale_and_shift(np.concatenate(cur), np.concatenate(ref),
+                                               np.concatenate(np.ones_like(ref) == 1))
+
+        def fit(d):
+            return np.maximum(d * scale + shift, 0)
+
+        post = [fit(d) for d in depth_list[base + align_len: base + OVERLAP]]
+        out[-INTERP_LEN:] = get_interpolate_frames(out[-INTERP_LEN:], post)
+        out.extend(fit(depth_list[base + i]) for i in range(OVERLAP, INFER_LEN))
+        ref = ref[:1] + [fit(depth_list[base + k]) for k in kfs[1:]]
+    return np.stack(out[:org_len], axis=0)

@@ -1,0 +1,74 @@
+"""Drop-in for video_depth_anything/video_depth.py:35-156 (VideoDepthAnything) on libvdn_hip.so."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import modules, util
+from .depth_anything_v2 import _EngineOwner
+from .engine import DPTEngine, EncoderEngine
+
+INFER_LEN, OVERLAP, KEYFRAMES, INTERP_LEN = util.INFER_LEN, util.OVERLAP, util.KEYFRAMES, util.INTERP_LEN
+
+
+class VideoDepthAnything(_EngineOwner):
+    def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False,
+                 use_clstoken=False, num_frames=32, pe="ape"):
+        super().__init__()
+        if use_bn or use_clstoken or pe != "ape":
+            raise NotImplementedError("only the configuration the reference ships (no bn/clstoken, pe='ape')")
+        if encoder not in ("vits", "vitl"):
+            raise KeyError(encoder)  # video_depth.py:48-51
+        self.intermediate_layer_idx = {"vits": [2, 5, 8, 11], "vitl": [4, 11, 17, 23]}
+        self.encoder = encoder
+        cfg = modules.ENCODERS[encoder]
+        self.pretrained = modules.dinov2(encoder)
+        self.head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames)
+        self._features, self._out_channels = features, list(out_channels)
+
+    def _engines(self):
+        if self._eng is None:
+            rt = self._runtime()
+            cfg = modules.ENCODERS[self.encoder]
+            self._eng = dict(rt=rt, enc=EncoderEngine(rt, self.pretrained, cfg),
+                             head=DPTEngine(rt, self.head, cfg["dim"], self._features, self._out_channels, temporal=True))
+        return self._eng
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, _pre_relu: bool = False) -> torch.Tensor:
+        """x [B,T,3,H,W] -> [B,T,H,W] (video_depth.py:58-65). The final resize to (H,W) is the identity
+        because H = 14*ph, so it is skipped."""
+        e = self._engines()
+        rt, enc, head = e["rt"], e["enc"], e["head"]
+        B, T, _, H, W = x.shape
+        xf = x.to(device=rt.device, dtype=torch.float32).reshape(B * T, 3, H, W).contiguous()
+        taps, _, (ph, pw) = enc.run(xf)
+        depth = head.run(taps, B * T, ph, pw, T=T, relu=not _pre_relu)
+        return depth.reshape(B, T, H, W).clone()
+
+    @torch.no_grad()
+    def infer_video_depth(self, frames: np.ndarray, target_fps, input_size: int = 518, device: str = "cuda",
+                          fp32: bool = False):
+        """frames u8 RGB [N,h,w,3] -> (f32 [N,h,w], target_fps) (video_depth.py:67-156). `fp32` is accepted for
+        signature compatibility; operands are always 16-bit with fp32 accumulation."""
+        e = self._engines()
+        rt = e["rt"]
+        fh, fw = frames[0].shape[:2]
+        ratio = max(fh, fw) / min(fh, fw)
+        if ratio > 1.78:
+            input_size = int(input_size * 1.777 / ratio)
+            input_size = round(input_size / 14) * 14
+        n = frames.shape[0]
+        dev_frames = torch.from_numpy(np.ascontiguousarray(frames)).to(rt.device).float() / 255.0
+        net_in = self.preprocess(rt, dev_frames, input_size)  # [n,3,H,W]
+        depth_list = []
+        for idxs in util.window_table(n):
+            cur = net_in[torch.tensor(idxs, device=rt.device)][None]
+            d = self.forward(cur)[0]  # [32,H,W]
+            if tuple(d.shape[-2:]) != (fh, fw):
+                o = torch.empty((INFER_LEN, fh, fw), dtype=torch.float32, device=rt.device)
+                rt.upsample_f32(d.contiguous(), o, INFER_LEN, d.shape[-2], d.shape[-1], fh, fw)
+                d = o
+            dn = d.cpu().numpy()
+            depth_list += [dn[i] for i in range(INFER_LEN)]
+        return util.stitch(depth_list, n), target_fps
