@@ -100,6 +100,18 @@ typedef struct vdn_gemm_desc {
    * out NHWC [cB, cH*ck, cW*ck, cout]                                                            */
   int32_t ck, cout;
   const void* zeros;     /* >= 16 bytes of zeros (conv padding taps / K tail read from here)      */
+  /* Split-precision ("x3") planes, all optional. A 16-bit tensor t may come with a second plane
+   * t_lo = half(t_exact - float(t_hi)); the kernel then accumulates
+   *     A_hi*W_hi  +  A_hi*W_lo (if W_lo)  +  A_lo*W_hi (if A_lo)
+   * as extra K segments of the same MFMA loop (fp32-faithful to ~2^-21 instead of 2^-11), and
+   * half outputs are written as (hi = round-toward-zero, lo = remainder) when out_lo / dst_lo is
+   * given. hi and lo share their sign, so relu_a acts on each plane independently.              */
+  const void* A_lo;
+  const void* W_lo;
+  void* out_lo;
+  void* dst_lo[3];
+  const void* res1_lo;
+  const void* res2_lo;
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
@@ -114,38 +126,40 @@ int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
  *   and writes the remaining rows compacted.                                                     */
 int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
                   const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
-                  int out_group, void* out_h, int h_dt, float* out_f, vdn_stream stream);
+                  int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f, vdn_stream stream);
 
 /* Fused attention forward, head_dim 64: out[b, q, h*64+e] = softmax(scale * Q K^T) V.
  *   Q  half [BH, nq_pad, 64] (rows >= nq never read), K half [BH, nk_pad, 64],
  *   Vt half [BH, 64, nk_pad] (dim-major; columns >= nk must be finite), nk_pad % 64 == 0.
  * Scores never touch HBM. Replaces dinov2_layers/attention.py:53-59 and
  * F.scaled_dot_product_attention at sam2/modeling/sam/transformer.py:306.                        */
-int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out,
-                   int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
+int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
+                   const void* K_lo, const void* Vt_lo, void* out_lo, int B, int H, int nq, int nq_pad, int nk,
+                   int nk_pad, float scale, vdn_stream stream);
 
 /* Temporal attention over <=32 frames per (pixel, head): qkv half [(b f), D, 3c] packed
  * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)
  * with the rearranges of motion_module.py:255,320.                                              */
-int vdn_temporal_attn(int dt, const void* qkv, void* out, int Bv, int T, int D, int c, int heads,
-                      float scale, vdn_stream stream);
+int vdn_temporal_attn(int dt, const void* qkv, void* out, const void* qkv_lo, void* out_lo, int Bv, int T, int D,
+                      int c, int heads, float scale, vdn_stream stream);
 
 /* GroupNorm over NHWC half [F, HW, C] (fp32 stats per (frame, group)); `partial` is
  * f32 [F, nsplit, groups, 2] scratch. Replaces motion_module.py:112 (32 groups, eps 1e-6).       */
-int vdn_groupnorm(int dt, const void* x, void* y, int F, int HW, int C, int groups, const float* w,
-                  const float* b, float eps, float* partial, int nsplit, vdn_stream stream);
+int vdn_groupnorm(int dt, const void* x, const void* x_lo, void* y, void* y_lo, int F, int HW, int C, int groups,
+                  const float* w, const float* b, float eps, float* partial, int nsplit, vdn_stream stream);
 
 /* Bilinear resize, align_corners=True, NHWC half (C % 8 == 0) or single-channel f32.
  * Replaces F.interpolate at util/blocks.py:144, dpt.py:147, depth_anything_v2.py:63,
  * video_depth.py:63.                                                                             */
-int vdn_upsample_bilinear(int dt, const void* x, void* y, int B, int IH, int IW, int OH, int OW, int C,
-                          vdn_stream stream);
+int vdn_upsample_bilinear(int dt, const void* x, const void* x_lo, void* y, void* y_lo, int B, int IH, int IW, int OH,
+                          int OW, int C, vdn_stream stream);
 int vdn_upsample_bilinear_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int relu,
                               vdn_stream stream);
 
 /* f32 NCHW image [B,3,H,W] -> half rows [B*ph*pw, ldk] with k = (c*14+ky)*14+kx, zero tail.
  * (the im2col-free view of PatchEmbed's 14x14 stride-14 conv, patch_embed.py:76)                 */
-int vdn_patchify(int dt, const float* img, void* rows, int B, int H, int W, int ldk, vdn_stream stream);
+int vdn_patchify(int dt, const float* img, void* rows, void* rows_lo, int B, int H, int W, int ldk,
+                 vdn_stream stream);
 
 /* x[b*rows_per_b + row, :] = vec[:] (cls_token + pos_embed[0], dinov2.py:219-220)                */
 int vdn_fill_row(float* x, const float* vec, int B, int rows_per_b, int row, int C, vdn_stream stream);
@@ -162,8 +176,8 @@ int vdn_add_vec(const float* x, const float* vec, float alpha, float* y, int row
 
 /* depth[m] = (relu?) (bias + sum_c w[c] * feat[m, c]), feat half [M, C<=64] already ReLU'd
  * (the 1x1 conv + ReLU closing output_conv2, dpt.py:111-112)                                      */
-int vdn_head_out(int dt, const void* feat, const float* w, float bias, float* depth, int M, int C,
-                 int relu, vdn_stream stream);
+int vdn_head_out(int dt, const void* feat, const void* feat_lo, const float* w, float bias, float* depth, int M,
+                 int C, int relu, vdn_stream stream);
 
 /* MaskDownSampler stages of memory_block.py:72-75 (sam2/modeling/memory_encoder.py:36-58):
  * stage 1: sigmoid -> conv3x3 s2 p1 (1->4) -> LayerNorm2d -> GELU -> conv1x1 (4->1)
@@ -183,6 +197,7 @@ int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const floa
 int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);
 size_t vdn_sizeof_gemm_desc(void);      /* layout probes for FFI bindings */
 size_t vdn_offsetof_gemm_zeros(void);
+size_t vdn_offsetof_gemm_res2_lo(void);
 const char* vdn_version(void);
 int vdn_arch_ok(void); /* 1 if device 0 is gfx950 */
 

@@ -13,11 +13,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _product(which, enc):
+def _product(which, enc, precision=None):
     import vdn
     cls = vdn.DepthAnythingV2 if which == "A" else vdn.VideoDepthAnything
     m = cls(**vdn.MODEL_CONFIGS[enc])
     m.load_state_dict(synth_sd(which, enc), strict=True)
+    if precision:
+        m.set_precision(precision)
     return m.to("cuda").eval()
 
 
@@ -145,3 +147,18 @@ def test_infer_image_shape():
     img = synth.frames_u8(1234, 1, 240, 240)[0][:, :, ::-1]
     d = model.infer_image(np.ascontiguousarray(img), input_size=266)
     assert d.shape == (240, 240) and np.isfinite(d).all()
+
+
+@pytest.mark.parametrize("precision,limit", [("f16", 3e-3), ("bf16", 3e-2)])
+def test_single_pass_modes_error_is_reported_and_bounded(precision, limit):
+    """The full-rate single-product modes: not fp32-faithful; their distance from
+    the reference is printed and bounded so that a regression (a wrong kernel) cannot hide in it."""
+    g = np.load(os.path.join(GOLD, "A_vitl_518.npz"))
+    sub = int(g["meta"][4])
+    model = _product("A", "vitl", precision)
+    x = inputs(2, 518, 518).reshape(2, 1, 3, 518, 518)
+    for t in range(2):
+        pre = model.forward(x[t].cuda(), _pre_relu=True).cpu()
+        e = rel_l2(torch.relu(pre[:, ::sub, ::sub]), np.maximum(g[f"pre_{t}"], 0))
+        print(f"[A_vitl_518 {precision}] frame {t}: vs reference fixture post-ReLU {e:.2e}")
+        assert e < limit

@@ -397,3 +397,136 @@ def test_bf16_operand_mode(rt):
     o = torch.empty(1, nq, 128, device=DEV, dtype=torch.bfloat16)
     rb.flash_attn(q[0].bfloat16().contiguous().to(DEV), kd, vd, o, 1, 2, nq, nq, nk, 128, 0.125)
     close(o, ref, 1.5e-2)
+
+
+# --------------------------------------------------------------------------------------------- split precision
+@pytest.fixture(scope="module")
+def rt3():
+    from vdn.runtime import Runtime
+    return Runtime(torch.device("cuda:0"), torch.float16, split=True)
+
+
+def test_x3_gemm_is_fp32_faithful(rt3):
+    """hi/lo planes on both operands: error vs the UNROUNDED fp32 product drops from ~4e-4 to ~1e-6."""
+    from vdn import pack, _abi
+    M, N, K = 300, 192, 520
+    a = rnd(M, K, seed=200)
+    w = rnd(N, K, seed=201, scale=1 / math.sqrt(K))
+    b = rnd(N, seed=202)
+    ref = F.gelu(a.double() @ w.double().t() + b.double()).float()
+    out = torch.empty(M, N, device=DEV)
+    rt3.gemm(rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec), M, N, K, out=out, bias=b.to(DEV), act=_abi.ACT_GELU)
+    close(out, ref, 3e-6)
+    # half output written as planes
+    oh = rt3.hbuf("t_x3_out", (M, N))
+    rt3.gemm(rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec), M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU)
+    close(oh.float(), ref, 3e-6)
+    assert bool(((oh.hi.float() * oh.lo.float()) >= 0).all())  # planes share their sign
+
+
+def test_x3_conv_relu_residual(rt3):
+    from vdn import pack, _abi
+    B, H, W, Ci, Co = 2, 13, 11, 48, 64
+    x = rnd(B, H, W, Ci, seed=210)
+    w = rnd(Co, Ci, 3, 3, seed=211, scale=1 / math.sqrt(9 * Ci))
+    b = rnd(Co, seed=212)
+    r1 = rnd(B * H * W, Co, seed=213)
+    ref = F.conv2d(F.relu(x).permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ref = (F.relu(ref) + r1.double()).float()
+    # the A planes must come from the device split (round-toward-zero hi) for relu_a to be plane-wise
+    xa = rt3.hbuf("t_x3_a", (B * H * W, Ci))
+    xf = x.reshape(-1, Ci).to(DEV)
+    # RTZ split on the host: hi = trunc-toward-zero to fp16
+    h_rtn = xf.half()
+    over = h_rtn.float().abs() > xf.abs()
+    step = torch.nextafter(h_rtn, torch.zeros_like(h_rtn))
+    hi = torch.where(over, step, h_rtn)
+    xa.hi.copy_(hi)
+    xa.lo.copy_((xf - hi.float()).half())
+    out = rt3.hbuf("t_x3_o", (B * H * W, Co))
+    rt3.gemm(xa, pack.conv3x3(w.to(DEV), rt3.prec), B * H * W, Co, 9 * Ci, out=out, bias=b.to(DEV), act=_abi.ACT_RELU,
+             relu_a=True, res1=rt3.to_half(r1.to(DEV)), conv=dict(B=B, H=H, W=W, C=Ci, OH=H, OW=W, stride=1))
+    close(out.float(), ref, 5e-6)
+
+
+def test_x3_heads_rope_and_flash(rt3):
+    from vdn import pack, _abi
+    from vdn.runtime import ceil_to
+    from oracle import ref_cpu as O
+    B, side, Hh = 1, 7, 2
+    P, C = side * side, Hh * 64
+    a = rnd(B * P, C, seed=220)
+    ws = [rnd(C, C, seed=221 + i, scale=1.5 / math.sqrt(C)) for i in range(3)]
+    bs = [rnd(C, seed=225 + i) for i in range(3)]
+    q, k, v = [(a.double() @ w.double().t() + b.double()).float().reshape(B, P, Hh, 64).transpose(1, 2) for w, b in zip(ws, bs)]
+    fc = O.compute_axial_cis(64, side, side)
+    q, k = O.apply_rotary_enc(q, k, fc, False)
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(1, 2).reshape(B, P, C)
+    wp, bp = pack.cat_proj([w.to(DEV) for w in ws], [b.to(DEV) for b in bs], [1, 1, 0], rt3.prec)
+    tp = ceil_to(P, 64)
+    qd, kd = rt3.hbuf("t_q", (B * Hh, tp, 64), zero=True), rt3.hbuf("t_k", (B * Hh, tp, 64), zero=True)
+    vd = rt3.hbuf("t_v", (B * Hh, 64, tp), zero=True)
+    cs = pack.rope_table(side, side, 64, device=DEV)
+    rt3.gemm(rt3.to_half(a.to(DEV)), wp, B * P, 3 * C, C, bias=bp, store=_abi.ST_HEADS,
+             heads=dict(dst=[qd, kd, vd], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=tp))
+    close(qd.float().reshape(B, Hh, tp, 64)[:, :, :P], q, 5e-6)
+    close(vd.float().reshape(B, Hh, 64, tp)[:, :, :, :P], v.transpose(2, 3), 5e-6)
+    out = rt3.hbuf("t_o", (B * P, C))
+    rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125)
+    close(out.float().reshape(B, P, C), ref, 1e-5)
+
+
+@pytest.mark.parametrize("nq,nk", [(150, 200), (1370, 1370)])
+def test_x3_flash_attention(rt3, nq, nk):
+    from vdn.runtime import ceil_to
+    B, H = 1, 2
+    q, k, v = rnd(B, H, nq, 64, seed=230), rnd(B, H, nk, 64, seed=231), rnd(B, H, nk, 64, seed=232)
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(1, 2).reshape(B, nq, H * 64)
+    qp, kp = ceil_to(nq, 64), ceil_to(nk, 64)
+    qd, kd, vd = rt3.hbuf("t2_q", (B * H, qp, 64), zero=True), rt3.hbuf("t2_k", (B * H, kp, 64), zero=True), rt3.hbuf("t2_v", (B * H, 64, kp), zero=True)
+    for dst, src in ((qd, q.reshape(B * H, nq, 64)), (kd, k.reshape(B * H, nk, 64))):
+        s = rt3.to_half(src.to(DEV))
+        dst.hi[:, :src.shape[1]] = s.hi
+        dst.lo[:, :src.shape[1]] = s.lo
+    s = rt3.to_half(v.reshape(B * H, nk, 64).transpose(1, 2).contiguous().to(DEV))
+    vd.hi[:, :, :nk] = s.hi
+    vd.lo[:, :, :nk] = s.lo
+    out = rt3.hbuf("t2_o", (B * nq, H * 64))
+    rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
+    close(out.float().reshape(B, nq, H * 64), ref, 1e-5)
+
+
+def test_x3_temporal_norms_upsample_headout(rt3):
+    Bv, T, D, c = 1, 32, 5, 192
+    qkv = rnd(Bv * T, D, 3 * c, seed=240)
+    x = qkv.reshape(Bv, T, D, 3, 8, c // 8).permute(3, 0, 2, 4, 1, 5).double()
+    ref = F.scaled_dot_product_attention(x[0], x[1], x[2]).permute(0, 3, 1, 2, 4).reshape(Bv * T, D, c).float()
+    out = rt3.hbuf("t3_o", (Bv * T, D, c))
+    rt3.temporal_attn(rt3.to_half(qkv.to(DEV)), out, Bv, T, D, c, 8, (c // 8) ** -0.5)
+    close(out.float(), ref, 1e-5)
+    # LayerNorm -> planes
+    xs = rnd(40, 384, seed=241)
+    w, b = rnd(384, seed=242), rnd(384, seed=243)
+    o = rt3.hbuf("t3_ln", (40, 384))
+    rt3.layernorm(xs.to(DEV), 40, 384, w.to(DEV), b.to(DEV), 1e-6, out_h=o)
+    close(o.float(), F.layer_norm(xs, (384,), w, b, 1e-6), 2e-6)
+    # GroupNorm + upsample on planes
+    xg = rnd(2, 100, 64, seed=244)
+    refg = F.group_norm(xg.permute(0, 2, 1).reshape(2, 64, 100, 1), 32, w[:64], b[:64], 1e-6).reshape(2, 64, 100).permute(0, 2, 1)
+    y = rt3.hbuf("t3_gn", (2, 100, 64))
+    rt3.groupnorm(rt3.to_half(xg.to(DEV)), y, 2, 100, 64, 32, w[:64].contiguous().to(DEV), b[:64].contiguous().to(DEV), 1e-6)
+    close(y.float(), refg, 5e-6)
+    xu = rnd(1, 10, 10, 64, seed=245)
+    refu = F.interpolate(xu.permute(0, 3, 1, 2), (23, 17), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    yu = rt3.hbuf("t3_up", (1, 23, 17, 64))
+    rt3.upsample(rt3.to_half(xu.to(DEV)), yu, 1, 10, 10, 23, 17, 64)
+    close(yu.float(), refu, 3e-6)
+    f = F.relu(rnd(500, 32, seed=246))
+    wv = rnd(32, seed=247)
+    d = torch.empty(500, device=DEV)
+    rt3.head_out(rt3.to_half(f.to(DEV)), wv.to(DEV), 0.1, d, 500, 32, relu=False)
+    close(d, f @ wv + 0.1, 3e-6)
+    img = rnd(1, 3, 28, 28, seed=248)
+    rows = rt3.hbuf("t3_rows", (4, 640))
+    rt3.patchify(img.to(DEV), rows, 1, 28, 28, 640)
+    close(rows.float()[:, :588], F.unfold(img, 14, stride=14).transpose(1, 2).reshape(4, 588), 1e-6)

@@ -85,6 +85,30 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Split a float into (hi, lo) 16-bit planes: hi = x rounded TOWARD ZERO, lo = nearest(x - hi).
+// hi and lo share their sign (or lo == 0), so sign-based ops (ReLU) act per plane.
+__device__ __forceinline__ void split_rtz(float x, _Float16& hi, _Float16& lo) {
+  const f16x2 p = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
+  hi = p[0];
+  lo = (_Float16)(x - (float)hi);
+}
+__device__ __forceinline__ void split_rtz(float x, __bf16& hi, __bf16& lo) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u;  // truncate mantissa
+  const float h = __builtin_bit_cast(float, u);
+  hi = __builtin_bit_cast(__bf16, (uint16_t)(u >> 16));
+  lo = (__bf16)(x - h);
+}
+// store 1 value: hi-only (round to nearest) or split planes
+template <typename T>
+__device__ __forceinline__ void store_half(T* hi, T* lo, size_t i, float v) {
+  if (lo) { T a, b; split_rtz(v, a, b); hi[i] = a; lo[i] = b; }
+  else hi[i] = (T)v;
+}
+template <typename T>
+__device__ __forceinline__ float load_half(const T* hi, const T* lo, size_t i) {
+  return lo ? (float)hi[i] + (float)lo[i] : (float)hi[i];
+}
+
 // XCD-aware bijective block remap (guide §5 'XCD swizzle must be bijective'): blocks that share
 // blockIdx % 8 share an XCD/L2, so give each XCD a contiguous run of the logical tile order.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

@@ -70,9 +70,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
   const T* zeros = (const T*)p.zeros;
   const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
 
-  auto stage = [&](int buf, int kt) {
+  // K segments: [A_hi x W_hi] (+ [A_hi x W_lo]) (+ [A_lo x W_hi]) — the split-precision planes are
+  // just further stretches of the same accumulation loop, selected by a plane byte offset.
+  const int nk1 = p.ldb / BK;
+  const int seg_wlo = p.W_lo ? 1 : -1;
+  const int nseg = 1 + (p.W_lo ? 1 : 0) + (p.A_lo ? 1 : 0);
+  const int seg_alo = p.A_lo ? nseg - 1 : -1;
+  const ptrdiff_t a_delta = p.A_lo ? (const char*)p.A_lo - (const char*)p.A : 0;
+  const ptrdiff_t w_delta = p.W_lo ? (const char*)p.W_lo - (const char*)p.W : 0;
+
+  auto stage = [&](int buf, int kt_all) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_BYTES;
+    const int seg = kt_all / nk1;
+    const int kt = kt_all - seg * nk1;
+    const ptrdiff_t ad = (seg == seg_alo) ? a_delta : 0;
+    const ptrdiff_t wd = (seg == seg_wlo) ? w_delta : 0;
     const int k = kt * BK + chunk * 8;
     if constexpr (CONV) {
       // (tap, ci) of this lane's chunk; Cin % 8 == 0 so a chunk never straddles two taps
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
       for (int i = 0; i < A_IT; ++i) {
         const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
         const bool ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
-        const T* src = ok ? a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci : zeros;
+        const char* src = ok ? (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci) + ad : (const char*)zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
                                          16, 0, 0);
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
       const bool ok = k < p.K;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const T* src = ok ? a_row[i] + k : zeros;
+        const char* src = ok ? (const char*)(a_row[i] + k) + ad : (const char*)zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
                                          16, 0, 0);
@@ -101,7 +114,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_row[i] + k),
+      const char* src = (const char*)(b_row[i] + k) + wd;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sB + (i * 4 + wave) * 1024),
                                        16, 0, 0);
     }
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.ldb / BK;
+  const int nk = nk1 * nseg;
   stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -186,8 +200,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
         else if (p.act == VDN_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
         if (p.gamma) v[e] *= p.gamma[n + e];
         if (p.tab) v[e] += p.tab[(size_t)(m % p.tab_mod + p.tab_off) * p.N + n + e];
-        if (p.res1) v[e] += load_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n + e);
-        if (p.res2) v[e] += load_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n + e);
+        if (p.res1) {
+          v[e] += load_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n + e);
+          if (p.res1_lo) v[e] += load_as_float(p.res1_lo, p.res1_dt, (size_t)m * p.ldr1 + n + e);
+        }
+        if (p.res2) {
+          v[e] += load_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n + e);
+          if (p.res2_lo) v[e] += load_as_float(p.res2_lo, p.res2_dt, (size_t)m * p.ldr2 + n + e);
+        }
       }
       size_t o;
       if (p.store == VDN_ST_CONVT) {
@@ -202,6 +222,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
       }
       if (p.out_dt == VDN_F32) {
         *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else if (p.out_lo) {
+        typename H::V4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { T a, b; split_rtz(v[e], a, b); h[e] = a; l[e] = b; }
+        *(typename H::V4*)((T*)p.out + o) = h;
+        *(typename H::V4*)((T*)p.out_lo + o) = l;
       } else {
         typename H::V4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
         *(typename H::V4*)((T*)p.out + o) = h;
@@ -226,6 +252,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
       const size_t o = (size_t)m * p.ldc + (n0 >> 1) + oc;
       if (p.out_dt == VDN_F32) {
         *(f32x4*)((float*)p.out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else if (p.out_lo) {
+        typename H::V4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { T a, b; split_rtz(v[e], a, b); h[e] = a; l[e] = b; }
+        *(typename H::V4*)((T*)p.out + o) = h;
+        *(typename H::V4*)((T*)p.out_lo + o) = l;
       } else {
         typename H::V4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
         *(typename H::V4*)((T*)p.out + o) = h;
@@ -242,28 +274,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
       if (p.transposed[split]) continue;
       const int head = (n - split * hc) >> 6, e0 = n & 63;
       const int bt = m / p.tokens, tl = m - bt * p.tokens;
-      T* dst = (T*)p.dst[split] + (((size_t)bt * p.heads + head) * p.tpad + tl + p.tok_off) * 64;
+      const size_t doff = (((size_t)bt * p.heads + head) * p.tpad + tl + p.tok_off) * 64;
+      T* dst = (T*)p.dst[split] + doff;
+      T* dlo = p.dst_lo[split] ? (T*)p.dst_lo[split] + doff : nullptr;
       const f32x4 a = *(const f32x4*)(tileC + r * LDT + c);
       if (p.rope[split]) {
         if (e0 & 16) continue;  // imaginary tile: consumed by the thread owning the real tile
         const f32x4 b = *(const f32x4*)(tileC + r * LDT + c + 16);
         const int pi = ((e0 >> 5) << 4) + (e0 & 15);  // first of 4 consecutive pair indices
         const float* cs = p.rope_cs + (size_t)(tl % p.rope_mod) * 64 + 2 * pi;
-        typename H::V8 o8;
+        typename H::V8 o8, l8;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float re = a[e] + (p.bias ? p.bias[n + e] : 0.f);
           const float im = b[e] + (p.bias ? p.bias[n + 16 + e] : 0.f);
           const float cc = cs[2 * e], ss = cs[2 * e + 1];
-          o8[2 * e] = (T)(re * cc - im * ss);
-          o8[2 * e + 1] = (T)(re * ss + im * cc);
+          const float ore = re * cc - im * ss, oim = re * ss + im * cc;
+          if (dlo) {
+            T x0, x1, y0, y1;
+            split_rtz(ore, x0, x1);
+            split_rtz(oim, y0, y1);
+            o8[2 * e] = x0; l8[2 * e] = x1; o8[2 * e + 1] = y0; l8[2 * e + 1] = y1;
+          } else {
+            o8[2 * e] = (T)ore;
+            o8[2 * e + 1] = (T)oim;
+          }
         }
         *(typename H::V8*)(dst + 2 * pi) = o8;
+        if (dlo) *(typename H::V8*)(dlo + 2 * pi) = l8;
       } else {
-        typename H::V4 h;
+        typename H::V4 h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (T)(a[e] + (p.bias ? p.bias[n + e] : 0.f));
+        for (int e = 0; e < 4; ++e) {
+          const float v = a[e] + (p.bias ? p.bias[n + e] : 0.f);
+          if (dlo) { T x0, x1; split_rtz(v, x0, x1); h[e] = x0; l[e] = x1; }
+          else h[e] = (T)v;
+        }
         *(typename H::V4*)(dst + e0) = h;
+        if (dlo) *(typename H::V4*)(dlo + e0) = l;
       }
     }
     // pass 2: dim-major (V^T) splits, one thread = 4 consecutive tokens of one column, so that
@@ -281,12 +329,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
         const int head = (n - split * hc) >> 6, e = n & 63;
         const float bv = p.bias ? p.bias[n] : 0.f;
         T* dst = (T*)p.dst[split];
+        T* dlo = (T*)p.dst_lo[split];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int m = m0 + r + k;
           if (m >= p.M) break;
           const int bt = m / p.tokens, tl = m - bt * p.tokens;
-          dst[(((size_t)bt * p.heads + head) * 64 + e) * p.tpad + tl + p.tok_off] = (T)(tileC[(r + k) * LDT + c] + bv);
+          store_half(dst, dlo, (((size_t)bt * p.heads + head) * 64 + e) * p.tpad + tl + p.tok_off,
+                     tileC[(r + k) * LDT + c] + bv);
         }
       }
     }
@@ -336,6 +386,8 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
     return VDN_EUNSUPPORTED;
   }
   if (d.N & 3) return VDN_EALIGN;  // the epilogue stores 4 columns per lane
+  if (((uintptr_t)d.A_lo | (uintptr_t)d.W_lo | (uintptr_t)d.out_lo) & 15) return VDN_EALIGN;
+  if (d.out_lo && (d.out_dt == VDN_F32 || !d.out)) return VDN_EINVAL;
   switch (d.store) {
     case VDN_ST_PLAIN:
       if (!d.out || d.ldc < d.N) return VDN_EINVAL;

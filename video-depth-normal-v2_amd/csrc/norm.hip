@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
                                                         float eps, const float* __restrict__ addvec, float alpha,
                                                         const float* __restrict__ addtab, int tab_div, int tab_mod,
                                                         int out_group, typename Half<DT>::T* __restrict__ out_h,
+                                                        typename Half<DT>::T* __restrict__ out_l,
                                                         float* __restrict__ out_f) {
   using T = typename Half<DT>::T;
   const int lane = threadIdx.x & 63;
@@ -68,8 +69,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
       }
       if (out_f) *(f32x4*)(out_f + orow * C + c) = f32x4{y[0], y[1], y[2], y[3]};
       if (out_h) {
-        typename Half<DT>::V4 hv = {(T)y[0], (T)y[1], (T)y[2], (T)y[3]};
+        typename Half<DT>::V4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (out_l) { T a, b2; split_rtz(y[e], a, b2); hv[e] = a; lv[e] = b2; }
+          else hv[e] = (T)y[e];
+        }
         *(typename Half<DT>::V4*)(out_h + orow * C + c) = hv;
+        if (out_l) *(typename Half<DT>::V4*)(out_l + orow * C + c) = lv;
       }
     }
   }
@@ -78,7 +85,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
 // ---------------------------------------------------------------- GroupNorm (NHWC), 2 kernels
 // stats: grid (F, nsplit); deterministic: per-channel column sums in fixed order, then per group.
 template <int DT>
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const typename Half<DT>::T* __restrict__ x, int HW,
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const typename Half<DT>::T* __restrict__ x,
+                                                              const typename Half<DT>::T* __restrict__ xl, int HW,
                                                               int C, int groups, float* __restrict__ partial,
                                                               int nsplit) {
   using V8 = typename Half<DT>::V8;
@@ -93,12 +101,14 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const typename Hal
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
   if (my_pl < pl) {
-    const typename Half<DT>::T* xb = x + (size_t)f * HW * C + my_cv * 8;
+    const size_t xo = (size_t)f * HW * C + my_cv * 8;
     for (int p = p0 + my_pl; p < p1; p += pl) {
-      const V8 v = *(const V8*)(xb + (size_t)p * C);
+      const V8 v = *(const V8*)(x + xo + (size_t)p * C);
+      V8 vl;
+      if (xl) vl = *(const V8*)(xl + xo + (size_t)p * C);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float fv = (float)v[e];
+        const float fv = xl ? (float)v[e] + (float)vl[e] : (float)v[e];
         s[e] += fv;
         ss[e] += fv * fv;
       }
@@ -129,7 +139,9 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const typename Hal
 
 template <int DT>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const typename Half<DT>::T* __restrict__ x,
-                                                              typename Half<DT>::T* __restrict__ y, int HW, int C,
+                                                              const typename Half<DT>::T* __restrict__ xl,
+                                                              typename Half<DT>::T* __restrict__ y,
+                                                              typename Half<DT>::T* __restrict__ yl, int HW, int C,
                                                               int groups, const float* __restrict__ w,
                                                               const float* __restrict__ b, float eps,
                                                               const float* __restrict__ partial, int nsplit) {
@@ -155,19 +167,23 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const typename Hal
   const size_t nvec = (size_t)HW * (C >> 3);
   const size_t per = (nvec + gridDim.y - 1) / gridDim.y;
   const size_t v0 = per * blockIdx.y, v1 = (v0 + per < nvec) ? v0 + per : nvec;
-  const T* xb = x + (size_t)f * HW * C;
-  T* yb = y + (size_t)f * HW * C;
+  const size_t fo = (size_t)f * HW * C;
   const int cv = C >> 3;
   for (size_t i = v0 + threadIdx.x; i < v1; i += 256) {
     const int c0 = (int)(i % cv) * 8;
-    const V8 v = *(const V8*)(xb + i * 8);
-    V8 o;
+    const V8 v = *(const V8*)(x + fo + i * 8);
+    V8 vl, o, ol;
+    if (xl) vl = *(const V8*)(xl + fo + i * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + e, g = c / cg;
-      o[e] = (T)(((float)v[e] - mr[2 * g]) * mr[2 * g + 1] * w[c] + b[c]);
+      const float xv = xl ? (float)v[e] + (float)vl[e] : (float)v[e];
+      const float r = (xv - mr[2 * g]) * mr[2 * g + 1] * w[c] + b[c];
+      if (yl) { T a, b2; split_rtz(r, a, b2); o[e] = a; ol[e] = b2; }
+      else o[e] = (T)r;
     }
-    *(V8*)(yb + i * 8) = o;
+    *(V8*)(y + fo + i * 8) = o;
+    if (yl) *(V8*)(yl + fo + i * 8) = ol;
   }
 }
 
@@ -188,15 +204,15 @@ __global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restric
 
 template <typename XT>
 int ln_launch(const void* x, int rows, int C, const float* w, const float* b, float eps, const float* addvec,
-              float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, int h_dt,
-              float* out_f, hipStream_t s) {
+              float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, void* out_l,
+              int h_dt, float* out_f, hipStream_t s) {
   const dim3 grid((rows + 3) / 4);
   if (h_dt == VDN_BF16)
     hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
-                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, out_f);
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, (__bf16*)out_l, out_f);
   else
     hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
-                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, out_f);
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
@@ -205,7 +221,8 @@ int ln_launch(const void* x, int rows, int C, const float* w, const float* b, fl
 
 extern "C" int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
                              const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
-                             int out_group, void* out_h, int h_dt, float* out_f, vdn_stream stream) {
+                             int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f,
+                             vdn_stream stream) {
   if (!x || !w || !b || rows <= 0 || C <= 0 || (!out_h && !out_f)) return VDN_EINVAL;
   if ((C & 3) || C > 2048) return VDN_EALIGN;
   if (addtab && (tab_div <= 0 || tab_mod <= 0)) return VDN_EINVAL;
@@ -213,15 +230,16 @@ extern "C" int vdn_layernorm(const void* x, int x_dt, int rows, int C, const flo
   hipStream_t s = (hipStream_t)stream;
   if (!addtab) { tab_div = 1; tab_mod = 1; }
   switch (x_dt) {
-    case VDN_F32: return ln_launch<float>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, h_dt, out_f, s);
-    case VDN_F16: return ln_launch<_Float16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, h_dt, out_f, s);
-    case VDN_BF16: return ln_launch<__bf16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, h_dt, out_f, s);
+    case VDN_F32: return ln_launch<float>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, s);
+    case VDN_F16: return ln_launch<_Float16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, s);
+    case VDN_BF16: return ln_launch<__bf16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, s);
     default: return VDN_EUNSUPPORTED;
   }
 }
 
-extern "C" int vdn_groupnorm(int dt, const void* x, void* y, int F, int HW, int C, int groups, const float* w,
-                             const float* b, float eps, float* partial, int nsplit, vdn_stream stream) {
+extern "C" int vdn_groupnorm(int dt, const void* x, const void* x_lo, void* y, void* y_lo, int F, int HW, int C,
+                             int groups, const float* w, const float* b, float eps, float* partial, int nsplit,
+                             vdn_stream stream) {
   if (!x || !y || !w || !b || !partial || F <= 0 || HW <= 0 || groups <= 0 || groups > 64 || C % groups || nsplit <= 0)
     return VDN_EINVAL;
   if ((C & 7) || C > 2048) return VDN_EALIGN;
@@ -230,15 +248,15 @@ extern "C" int vdn_groupnorm(int dt, const void* x, void* y, int F, int HW, int 
   const size_t lds = (size_t)pl * C * 2 * sizeof(float);
   const int chunks = (int)(((size_t)HW * (C >> 3) + 256 * 8 - 1) / (256 * 8));
   if (dt == VDN_F16) {
-    hipLaunchKernelGGL(groupnorm_stats_kernel<VDN_F16>, dim3(F, nsplit), dim3(256), lds, s, (const _Float16*)x, HW, C,
-                       groups, partial, nsplit);
+    hipLaunchKernelGGL(groupnorm_stats_kernel<VDN_F16>, dim3(F, nsplit), dim3(256), lds, s, (const _Float16*)x,
+                       (const _Float16*)x_lo, HW, C, groups, partial, nsplit);
     hipLaunchKernelGGL(groupnorm_apply_kernel<VDN_F16>, dim3(F, chunks), dim3(256), 0, s, (const _Float16*)x,
-                       (_Float16*)y, HW, C, groups, w, b, eps, partial, nsplit);
+                       (const _Float16*)x_lo, (_Float16*)y, (_Float16*)y_lo, HW, C, groups, w, b, eps, partial, nsplit);
   } else if (dt == VDN_BF16) {
-    hipLaunchKernelGGL(groupnorm_stats_kernel<VDN_BF16>, dim3(F, nsplit), dim3(256), lds, s, (const __bf16*)x, HW, C,
-                       groups, partial, nsplit);
+    hipLaunchKernelGGL(groupnorm_stats_kernel<VDN_BF16>, dim3(F, nsplit), dim3(256), lds, s, (const __bf16*)x,
+                       (const __bf16*)x_lo, HW, C, groups, partial, nsplit);
     hipLaunchKernelGGL(groupnorm_apply_kernel<VDN_BF16>, dim3(F, chunks), dim3(256), 0, s, (const __bf16*)x,
-                       (__bf16*)y, HW, C, groups, w, b, eps, partial, nsplit);
+                       (const __bf16*)x_lo, (__bf16*)y, (__bf16*)y_lo, HW, C, groups, w, b, eps, partial, nsplit);
   } else {
     return VDN_EUNSUPPORTED;
   }

@@ -16,7 +16,9 @@ __device__ __forceinline__ void ac_coord(int o, float scale, int in, int& i0, in
 
 template <int DT>
 __global__ __launch_bounds__(256) void upsample_kernel(const typename Half<DT>::T* __restrict__ x,
-                                                       typename Half<DT>::T* __restrict__ y, int B, int IH, int IW,
+                                                       const typename Half<DT>::T* __restrict__ xl,
+                                                       typename Half<DT>::T* __restrict__ y,
+                                                       typename Half<DT>::T* __restrict__ yl, int B, int IH, int IW,
                                                        int OH, int OW, int C) {
   using T = typename Half<DT>::T;
   using V8 = typename Half<DT>::V8;
@@ -35,19 +37,28 @@ __global__ __launch_bounds__(256) void upsample_kernel(const typename Half<DT>::
     float ly, lx;
     ac_coord(oy, sy, IH, y0, y1, ly);
     ac_coord(ox, sx, IW, x0, x1, lx);
-    const T* xb = x + (size_t)b * IH * IW * C + c8 * 8;
-    const V8 v00 = *(const V8*)(xb + ((size_t)y0 * IW + x0) * C);
-    const V8 v01 = *(const V8*)(xb + ((size_t)y0 * IW + x1) * C);
-    const V8 v10 = *(const V8*)(xb + ((size_t)y1 * IW + x0) * C);
-    const V8 v11 = *(const V8*)(xb + ((size_t)y1 * IW + x1) * C);
-    V8 o;
+    const size_t xo = (size_t)b * IH * IW * C + c8 * 8;
+    const size_t o00 = xo + ((size_t)y0 * IW + x0) * C, o01 = xo + ((size_t)y0 * IW + x1) * C;
+    const size_t o10 = xo + ((size_t)y1 * IW + x0) * C, o11 = xo + ((size_t)y1 * IW + x1) * C;
+    const V8 v00 = *(const V8*)(x + o00), v01 = *(const V8*)(x + o01);
+    const V8 v10 = *(const V8*)(x + o10), v11 = *(const V8*)(x + o11);
+    V8 l00, l01, l10, l11, o, ol;
+    if (xl) {
+      l00 = *(const V8*)(xl + o00); l01 = *(const V8*)(xl + o01);
+      l10 = *(const V8*)(xl + o10); l11 = *(const V8*)(xl + o11);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float top = (1.f - lx) * (float)v00[e] + lx * (float)v01[e];
-      const float bot = (1.f - lx) * (float)v10[e] + lx * (float)v11[e];
-      o[e] = (T)((1.f - ly) * top + ly * bot);
+      float a00 = (float)v00[e], a01 = (float)v01[e], a10 = (float)v10[e], a11 = (float)v11[e];
+      if (xl) { a00 += (float)l00[e]; a01 += (float)l01[e]; a10 += (float)l10[e]; a11 += (float)l11[e]; }
+      const float top = (1.f - lx) * a00 + lx * a01;
+      const float bot = (1.f - lx) * a10 + lx * a11;
+      const float r = (1.f - ly) * top + ly * bot;
+      if (yl) { T a, b2; split_rtz(r, a, b2); o[e] = a; ol[e] = b2; }
+      else o[e] = (T)r;
     }
     *(V8*)(y + i * 8) = o;
+    if (yl) *(V8*)(yl + i * 8) = ol;
   }
 }
 
@@ -76,7 +87,8 @@ __global__ __launch_bounds__(256) void upsample_f32_kernel(const float* __restri
 
 template <int DT>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
-                                                       typename Half<DT>::T* __restrict__ rows, int B, int H, int W,
+                                                       typename Half<DT>::T* __restrict__ rows,
+                                                       typename Half<DT>::T* __restrict__ rows_lo, int B, int H, int W,
                                                        int ldk) {
   using T = typename Half<DT>::T;
   using V8 = typename Half<DT>::V8;
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const size_t t = row / pw;
     const int py = (int)(t % ph);
     const int b = (int)(t / ph);
-    V8 o;
+    V8 o, ol;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = k8 * 8 + e;
@@ -100,9 +112,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const int ky = rem / 14, kx = rem - ky * 14;
         v = img[(((size_t)b * 3 + c) * H + py * 14 + ky) * W + px * 14 + kx];
       }
-      o[e] = (T)v;
+      if (rows_lo) { T a, b2; split_rtz(v, a, b2); o[e] = a; ol[e] = b2; }
+      else o[e] = (T)v;
     }
     *(V8*)(rows + i * 8) = o;
+    if (rows_lo) *(V8*)(rows_lo + i * 8) = ol;
   }
 }
 
@@ -158,6 +172,7 @@ __global__ void bicubic_kernel(const float* __restrict__ src, float* __restrict_
 
 template <int DT>
 __global__ __launch_bounds__(256) void head_out_kernel(const typename Half<DT>::T* __restrict__ feat,
+                                                       const typename Half<DT>::T* __restrict__ feat_lo,
                                                        const float* __restrict__ w, float bias,
                                                        float* __restrict__ depth, int M, int C, int relu) {
   using V8 = typename Half<DT>::V8;
@@ -170,6 +185,11 @@ __global__ __launch_bounds__(256) void head_out_kernel(const typename Half<DT>::
       const V8 v = *(const V8*)(feat + m * C + c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += sw[c + e] * (float)v[e];
+      if (feat_lo) {
+        const V8 vl = *(const V8*)(feat_lo + m * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += sw[c + e] * (float)vl[e];
+      }
     }
     depth[m] = relu ? fmaxf(acc, 0.f) : acc;
   }
@@ -294,18 +314,18 @@ inline int grid_for(size_t work, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int vdn_upsample_bilinear(int dt, const void* x, void* y, int B, int IH, int IW, int OH, int OW, int C,
-                                     vdn_stream stream) {
+extern "C" int vdn_upsample_bilinear(int dt, const void* x, const void* x_lo, void* y, void* y_lo, int B, int IH,
+                                     int IW, int OH, int OW, int C, vdn_stream stream) {
   if (!x || !y || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0) return VDN_EINVAL;
   if ((C & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VDN_EALIGN;
   const int g = grid_for((size_t)B * OH * OW * (C >> 3), 16384);
   hipStream_t s = (hipStream_t)stream;
   if (dt == VDN_F16)
-    hipLaunchKernelGGL(upsample_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, (const _Float16*)x, (_Float16*)y, B, IH, IW,
-                       OH, OW, C);
+    hipLaunchKernelGGL(upsample_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, (const _Float16*)x, (const _Float16*)x_lo,
+                       (_Float16*)y, (_Float16*)y_lo, B, IH, IW, OH, OW, C);
   else if (dt == VDN_BF16)
-    hipLaunchKernelGGL(upsample_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y, B, IH, IW, OH,
-                       OW, C);
+    hipLaunchKernelGGL(upsample_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)x_lo,
+                       (__bf16*)y, (__bf16*)y_lo, B, IH, IW, OH, OW, C);
   else
     return VDN_EUNSUPPORTED;
   VDN_CHECK_LAUNCH();
@@ -321,15 +341,18 @@ extern "C" int vdn_upsample_bilinear_f32(const float* x, float* y, int B, int IH
   return VDN_OK;
 }
 
-extern "C" int vdn_patchify(int dt, const float* img, void* rows, int B, int H, int W, int ldk, vdn_stream stream) {
+extern "C" int vdn_patchify(int dt, const float* img, void* rows, void* rows_lo, int B, int H, int W, int ldk,
+                            vdn_stream stream) {
   if (!img || !rows || B <= 0 || H <= 0 || W <= 0 || H % 14 || W % 14) return VDN_EINVAL;
   if (ldk < 588 || (ldk & 63) || ((uintptr_t)rows & 15)) return VDN_EALIGN;
   const int g = grid_for((size_t)B * (H / 14) * (W / 14) * (ldk >> 3), 8192);
   hipStream_t s = (hipStream_t)stream;
   if (dt == VDN_F16)
-    hipLaunchKernelGGL(patchify_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, img, (_Float16*)rows, B, H, W, ldk);
+    hipLaunchKernelGGL(patchify_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, img, (_Float16*)rows, (_Float16*)rows_lo, B, H, W,
+                       ldk);
   else if (dt == VDN_BF16)
-    hipLaunchKernelGGL(patchify_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, img, (__bf16*)rows, B, H, W, ldk);
+    hipLaunchKernelGGL(patchify_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, img, (__bf16*)rows, (__bf16*)rows_lo, B, H, W,
+                       ldk);
   else
     return VDN_EUNSUPPORTED;
   VDN_CHECK_LAUNCH();
@@ -354,18 +377,18 @@ extern "C" int vdn_bicubic(const float* src, float* dst, int ih, int iw, int oh,
   return VDN_OK;
 }
 
-extern "C" int vdn_head_out(int dt, const void* feat, const float* w, float bias, float* depth, int M, int C, int relu,
-                            vdn_stream stream) {
+extern "C" int vdn_head_out(int dt, const void* feat, const void* feat_lo, const float* w, float bias, float* depth,
+                            int M, int C, int relu, vdn_stream stream) {
   if (!feat || !w || !depth || M <= 0 || C <= 0 || C > 64) return VDN_EINVAL;
   if ((C & 7) || ((uintptr_t)feat & 15)) return VDN_EALIGN;
   const int g = grid_for((size_t)M, 8192);
   hipStream_t s = (hipStream_t)stream;
   if (dt == VDN_F16)
-    hipLaunchKernelGGL(head_out_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, (const _Float16*)feat, w, bias, depth, M, C,
-                       relu);
+    hipLaunchKernelGGL(head_out_kernel<VDN_F16>, dim3(g), dim3(256), 0, s, (const _Float16*)feat,
+                       (const _Float16*)feat_lo, w, bias, depth, M, C, relu);
   else if (dt == VDN_BF16)
-    hipLaunchKernelGGL(head_out_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, (const __bf16*)feat, w, bias, depth, M, C,
-                       relu);
+    hipLaunchKernelGGL(head_out_kernel<VDN_BF16>, dim3(g), dim3(256), 0, s, (const __bf16*)feat,
+                       (const __bf16*)feat_lo, w, bias, depth, M, C, relu);
   else
     return VDN_EUNSUPPORTED;
   VDN_CHECK_LAUNCH();
@@ -404,6 +427,7 @@ extern "C" int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C,
 
 extern "C" size_t vdn_sizeof_gemm_desc(void) { return sizeof(vdn_gemm_desc); }
 extern "C" size_t vdn_offsetof_gemm_zeros(void) { return offsetof(vdn_gemm_desc, zeros); }
+extern "C" size_t vdn_offsetof_gemm_res2_lo(void) { return offsetof(vdn_gemm_desc, res2_lo); }
 
 extern "C" const char* vdn_version(void) { return "vdn-hip 0.1 (gfx950)"; }
 

@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("transposed", i32 * 3), ("rope", i32 * 3),
         ("rope_cs", fp), ("rope_mod", i32),
         ("ck", i32), ("cout", i32), ("zeros", vp),
+        ("A_lo", vp), ("W_lo", vp), ("out_lo", vp), ("dst_lo", vp * 3), ("res1_lo", vp), ("res2_lo", vp),
     ]
 
 
@@ -55,24 +56,26 @@ lib = _load()
 EXPORTS = {
     "vdn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "vdn_layernorm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_float, fp, C.c_int, C.c_int,
-                                C.c_int, vp, C.c_int, fp, vp]),
-    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_float, vp]),
-    "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
-    "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_int, vp]),
-    "vdn_upsample_bilinear": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+                                C.c_int, vp, vp, C.c_int, fp, vp]),
+    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_float, vp]),
+    "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp,
+                                C.c_int, vp]),
+    "vdn_upsample_bilinear": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_upsample_bilinear_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    "vdn_patchify": (C.c_int, [C.c_int, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_patchify": (C.c_int, [C.c_int, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_fill_row": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_bicubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "vdn_add_vec": (C.c_int, [fp, fp, C.c_float, fp, C.c_int, C.c_int, vp]),
-    "vdn_head_out": (C.c_int, [C.c_int, vp, fp, C.c_float, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_head_out": (C.c_int, [C.c_int, vp, vp, fp, C.c_float, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_mask_down1": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_mask_down2": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_dwconv7": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
     "vdn_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_size_t, vp]),
     "vdn_sizeof_gemm_desc": (C.c_size_t, []),
     "vdn_offsetof_gemm_zeros": (C.c_size_t, []),
+    "vdn_offsetof_gemm_res2_lo": (C.c_size_t, []),
     "vdn_version": (C.c_char_p, []),
     "vdn_arch_ok": (C.c_int, []),
 }
@@ -82,7 +85,8 @@ for _name, (_res, _args) in EXPORTS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.vdn_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.vdn_offsetof_gemm_zeros() != GemmDesc.zeros.offset:
+if (lib.vdn_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.vdn_offsetof_gemm_zeros() != GemmDesc.zeros.offset
+        or lib.vdn_offsetof_gemm_res2_lo() != GemmDesc.res2_lo.offset):
     raise ImportError("vdn_gemm_desc layout mismatch between include/vdn.h and vdn/_abi.py — rebuild the library")
 
 

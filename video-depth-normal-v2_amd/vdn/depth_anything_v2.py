@@ -16,8 +16,20 @@ _MEAN = (0.485, 0.456, 0.406)
 _STD = (0.229, 0.224, 0.225)
 
 
-def _half_dtype():
-    return torch.bfloat16 if os.environ.get("VDN_HALF", "f16").lower() in ("bf16", "bfloat16") else torch.float16
+PRECISIONS = {"f16x3": (torch.float16, True), "f16": (torch.float16, False),
+              "bf16x3": (torch.bfloat16, True), "bf16": (torch.bfloat16, False)}
+DEFAULT_PRECISION = "f16x3"
+
+
+def _precision(name=None):
+    """MFMA operand precision:
+      f16x3 (default)  every 16-bit operand carried as hi+lo planes, 3 MFMA products per term —
+                       fp32-faithful, meets the 1e-3 parity bar on every fixture;
+      f16 / bf16       single product, full MFMA rate; ~1e-3..2.5e-3 from the fp32 reference."""
+    name = (name or os.environ.get("VDN_PRECISION", DEFAULT_PRECISION)).lower()
+    if name not in PRECISIONS:
+        raise ValueError(f"VDN_PRECISION must be one of {sorted(PRECISIONS)}, got {name!r}")
+    return name, PRECISIONS[name]
 
 
 class _EngineOwner(nn.Module):
@@ -26,6 +38,12 @@ class _EngineOwner(nn.Module):
     def __init__(self):
         super().__init__()
         self._eng = None
+        self.precision = None  # None -> $VDN_PRECISION -> DEFAULT_PRECISION
+
+    def set_precision(self, name: str):
+        _precision(name)
+        self.precision, self._eng = name, None
+        return self
 
     def _apply(self, fn, *a, **k):
         self._eng = None
@@ -37,7 +55,8 @@ class _EngineOwner(nn.Module):
 
     def _runtime(self) -> Runtime:
         dev = next(self.parameters()).device
-        return Runtime(dev, _half_dtype())
+        _, (dtype, split) = _precision(self.precision)
+        return Runtime(dev, dtype, split)
 
     @staticmethod
     def preprocess(rt: Runtime, frames_rgb01: torch.Tensor, input_size: int) -> torch.Tensor:

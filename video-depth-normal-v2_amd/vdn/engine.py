@@ -29,7 +29,7 @@ class EncoderEngine:
     def __init__(self, rt: Runtime, mod, cfg: dict):
         self.rt, self.cfg = rt, cfg
         self.C, self.heads, self.depth, self.taps = cfg["dim"], cfg["heads"], cfg["depth"], cfg["taps"]
-        h = rt.half
+        h = rt.prec
         self.w_patch = pack.patch_embed(mod.patch_embed.proj.weight, h)
         self.b_patch = pack.f32(mod.patch_embed.proj.bias)
         self.cls = pack.f32(mod.cls_token).reshape(-1)
@@ -116,7 +116,7 @@ class TemporalEngine:
 
     def __init__(self, rt: Runtime, mod, c: int, idx: int):
         self.rt, self.c, self.idx = rt, c, idx
-        h = rt.half
+        h = rt.prec
         tt = mod.temporal_transformer
         blk = tt.transformer_blocks[0]
         self.gnw, self.gnb = pack.f32(tt.norm.weight), pack.f32(tt.norm.bias)
@@ -168,7 +168,7 @@ class DPTEngine:
 
     def __init__(self, rt: Runtime, mod, in_ch: int, features: int, out_channels, temporal: bool):
         self.rt, self.C, self.F, self.oc = rt, in_ch, features, list(out_channels)
-        h = rt.half
+        h = rt.prec
         self.proj = [(pack.conv1x1(p.weight, h), pack.f32(p.bias)) for p in mod.projects]
         self.rt0 = pack.conv_transpose(mod.resize_layers[0].weight, mod.resize_layers[0].bias, h)
         self.rt1 = pack.conv_transpose(mod.resize_layers[1].weight, mod.resize_layers[1].bias, h)
@@ -287,7 +287,7 @@ class MemoryEngine:
 
     def __init__(self, rt: Runtime, mod, C: int, max_len: int):
         self.rt, self.C, self.heads, self.max_len = rt, C, C // 64, max_len
-        h = rt.half
+        h = rt.prec
         ma = mod.memory_attention
         self.layers = []
         for l in ma.layers:
@@ -306,7 +306,7 @@ class MemoryEngine:
                 w2=pack.linear(l.linear2.weight, h), b2=pack.f32(l.linear2.bias)))
         self.nw, self.nb = pack.f32(ma.norm.weight), pack.f32(ma.norm.bias)
         self.curr_pos = pack.f32(mod.curr_pos_enc).reshape(-1)
-        self.no_mem = mod.no_mem_embed.detach().reshape(1, -1).to(h)
+        self.no_mem = mod.no_mem_embed.detach().float().reshape(1, -1)
         me = mod.memory_encoder
 
         def flat(*ts):
@@ -372,8 +372,8 @@ class MemoryEngine:
         if S == 0:
             # empty bank: keys/values come from no_mem_embed broadcast to P tokens (memory_block.py:115-123)
             nk, nk_pad = P, pp
-            a_nm = rt.hbuf("ma_nomem_a", (M, C))
-            a_nm.copy_(self.no_mem.expand(M, C))
+            a_nm = rt.to_half(self.no_mem.expand(M, C).contiguous())
+            rt._keep.append(a_nm)
             ks = [rt.hbuf(f"nomem_k{l}", (B * Hh, pp, 64), zero=True) for l in range(len(self.layers))]
             vs = [rt.hbuf(f"nomem_vt{l}", (B * Hh, 64, pp), zero=True) for l in range(len(self.layers))]
             for l, L in enumerate(self.layers):

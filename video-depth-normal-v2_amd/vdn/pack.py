@@ -17,12 +17,22 @@ from typing import Optional, Tuple
 import torch
 
 
-def _pad_k(w2: torch.Tensor, half: torch.dtype) -> torch.Tensor:
+class Prec:
+    """Operand precision: 16-bit dtype + whether tensors carry a second (lo) plane."""
+
+    def __init__(self, dtype: torch.dtype, split: bool):
+        self.dtype, self.split = dtype, split
+
+
+def _pad_k(w2: torch.Tensor, half) -> "HL":
+    """f32 [N,K] -> HL of half [N, ceil64(K)] (zero tail). `half` is a Prec or a bare dtype."""
+    from .runtime import HL
+    prec = half if isinstance(half, Prec) else Prec(half, False)
     n, k = w2.shape
     kp = (k + 63) // 64 * 64
-    out = torch.zeros((n, kp), dtype=half, device=w2.device)
-    out[:, :k] = w2.to(half)
-    return out.contiguous()
+    full = torch.zeros((n, kp), dtype=torch.float32, device=w2.device)
+    full[:, :k] = w2
+    return HL.from_float(full, prec.dtype, prec.split)
 
 
 def linear(w: torch.Tensor, half) -> torch.Tensor:

@@ -26,12 +26,56 @@ def ceil_to(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+class HL:
+    """A 16-bit tensor as (hi, lo) planes; lo is None in single-precision-pass mode. In split ("x3")
+    mode value = float(hi) + float(lo) carries ~21 mantissa bits and every MFMA product is
+    accumulated as hi*hi + hi*lo + lo*hi (include/vdn.h)."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi: torch.Tensor, lo: Optional[torch.Tensor] = None):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def from_float(x: torch.Tensor, half: torch.dtype, split: bool) -> "HL":
+        hi = x.to(half)
+        if not split:
+            return HL(hi.contiguous())
+        lo = (x.float() - hi.float()).to(half)
+        return HL(hi.contiguous(), lo.contiguous())
+
+    def float(self) -> torch.Tensor:
+        return self.hi.float() if self.lo is None else self.hi.float() + self.lo.float()
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def data_ptr(self):
+        return self.hi.data_ptr()
+
+    def zero_(self):
+        self.hi.zero_()
+        if self.lo is not None:
+            self.lo.zero_()
+        return self
+
+
+def _hl(t):
+    """(hi tensor, lo pointer or None) of an HL or a plain tensor."""
+    if isinstance(t, HL):
+        return t.hi, (None if t.lo is None else t.lo.data_ptr())
+    return t, None
+
+
 class Runtime:
-    def __init__(self, device: torch.device, half: torch.dtype = torch.float16):
+    def __init__(self, device: torch.device, half: torch.dtype = torch.float16, split: bool = False):
         if device.type != "cuda":
             raise abi.VdnError("vdn kernels run on an MI355X ('cuda' device under ROCm); there is no CPU path")
         self.device = device
         self.half = half
+        self.split = split
+        from .pack import Prec
+        self.prec = Prec(half, split)
         self.dt = _TDT[half]
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)
         self._bufs: Dict[tuple, torch.Tensor] = {}
@@ -48,8 +92,12 @@ class Runtime:
             self._bufs[key] = t
         return t
 
-    def hbuf(self, name, shape, zero=False):
-        return self.buf(name, shape, self.half, zero)
+    def hbuf(self, name, shape, zero=False) -> HL:
+        hi = self.buf(name, shape, self.half, zero)
+        return HL(hi, self.buf(name + "#lo", shape, self.half, zero) if self.split else None)
+
+    def to_half(self, x: torch.Tensor) -> HL:
+        return HL.from_float(x, self.half, self.split)
 
     def fbuf(self, name, shape, zero=False):
         return self.buf(name, shape, torch.float32, zero)
@@ -99,6 +147,8 @@ class Runtime:
         d = abi.GemmDesc()
         d.dt = self.dt
         d.M, d.N, d.K = M, N, K
+        A, d.A_lo = _hl(A)
+        W, d.W_lo = _hl(W)
         d.A = A.data_ptr()
         d.relu_a = 1 if relu_a else 0
         if conv is not None:
@@ -112,6 +162,7 @@ class Runtime:
         d.W = W.data_ptr()
         d.ldb = W.shape[1]
         assert W.shape[0] == N and W.dtype == self.half and A.dtype == self.half, (W.shape, N, W.dtype, A.dtype)
+        assert W.is_contiguous()
         d.bias = self._p(bias)
         d.rowadd = self._p(rowadd)
         d.act = act
@@ -119,20 +170,24 @@ class Runtime:
         d.tab = self._p(tab)
         d.tab_mod, d.tab_off = tab_mod, tab_off
         if res1 is not None:
-            d.res1, d.res1_dt, d.ldr1 = res1.data_ptr(), _TDT[res1.dtype], (ldr1 if ldr1 is not None else N)
+            r1, d.res1_lo = _hl(res1)
+            d.res1, d.res1_dt, d.ldr1 = r1.data_ptr(), _TDT[r1.dtype], (ldr1 if ldr1 is not None else N)
         if res2 is not None:
-            d.res2, d.res2_dt, d.ldr2 = res2.data_ptr(), _TDT[res2.dtype], (ldr2 if ldr2 is not None else N)
+            r2, d.res2_lo = _hl(res2)
+            d.res2, d.res2_dt, d.ldr2 = r2.data_ptr(), _TDT[r2.dtype], (ldr2 if ldr2 is not None else N)
         d.store = store
         if out is not None:
-            d.out = out.data_ptr()
-            d.out_dt = _TDT[out.dtype]
+            oh, d.out_lo = _hl(out)
+            d.out = oh.data_ptr()
+            d.out_dt = _TDT[oh.dtype]
             d.ldc = ldc if ldc is not None else (N // 2 if store == abi.ST_GEGLU else N)
         d.row_group, d.row_skip = row_group, row_skip
         if heads is not None:
             dst = heads["dst"]
             d.nsplit = len(dst)
             for i, t in enumerate(dst):
-                d.dst[i] = t.data_ptr()
+                th, d.dst_lo[i] = _hl(t)
+                d.dst[i] = th.data_ptr()
                 d.transposed[i] = int(heads["transposed"][i])
                 d.rope[i] = int(heads.get("rope", (0, 0, 0))[i])
             d.heads, d.tokens, d.tok_off, d.tpad = heads["heads"], heads["tokens"], heads.get("tok_off", 0), heads["tpad"]
@@ -153,31 +208,37 @@ class Runtime:
 
     def layernorm(self, x: torch.Tensor, rows: int, Cn: int, w, b, eps: float, *, out_h=None, out_f=None, addvec=None,
                   alpha: float = 1.0, addtab=None, tab_div: int = 1, tab_mod: int = 1, out_group: int = 0):
+        oh, ol = _hl(out_h) if out_h is not None else (None, None)
         self._launch(abi.lib.vdn_layernorm, x.data_ptr(), _TDT[x.dtype], rows, Cn, w.data_ptr(), b.data_ptr(), eps,
-                     self._p(addvec), alpha, self._p(addtab), tab_div, tab_mod, out_group, self._p(out_h), self.dt,
+                     self._p(addvec), alpha, self._p(addtab), tab_div, tab_mod, out_group, self._p(oh), ol, self.dt,
                      self._p(out_f))
 
     def flash_attn(self, Q, K, Vt, out, B: int, H: int, nq: int, nq_pad: int, nk: int, nk_pad: int, scale: float):
-        self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), B, H,
-                     nq, nq_pad, nk, nk_pad, scale)
+        (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
+        self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
+                     vl, ol, B, H, nq, nq_pad, nk, nk_pad, scale)
 
     def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
-        self._launch(abi.lib.vdn_temporal_attn, self.dt, qkv.data_ptr(), out.data_ptr(), Bv, T, D, c, heads, scale)
+        (qkv, ql), (out, ol) = _hl(qkv), _hl(out)
+        self._launch(abi.lib.vdn_temporal_attn, self.dt, qkv.data_ptr(), out.data_ptr(), ql, ol, Bv, T, D, c, heads, scale)
 
     def groupnorm(self, x, y, F: int, HW: int, Cn: int, groups: int, w, b, eps: float):
         nsplit = 16 if HW >= 1024 else 4
         part = self.fbuf("gn_partial", (F, nsplit, groups, 2))
-        self._launch(abi.lib.vdn_groupnorm, self.dt, x.data_ptr(), y.data_ptr(), F, HW, Cn, groups, w.data_ptr(),
+        (x, xl), (y, yl) = _hl(x), _hl(y)
+        self._launch(abi.lib.vdn_groupnorm, self.dt, x.data_ptr(), xl, y.data_ptr(), yl, F, HW, Cn, groups, w.data_ptr(),
                      b.data_ptr(), eps, part.data_ptr(), nsplit)
 
     def upsample(self, x, y, B: int, IH: int, IW: int, OH: int, OW: int, Cn: int):
-        self._launch(abi.lib.vdn_upsample_bilinear, self.dt, x.data_ptr(), y.data_ptr(), B, IH, IW, OH, OW, Cn)
+        (x, xl), (y, yl) = _hl(x), _hl(y)
+        self._launch(abi.lib.vdn_upsample_bilinear, self.dt, x.data_ptr(), xl, y.data_ptr(), yl, B, IH, IW, OH, OW, Cn)
 
     def upsample_f32(self, x, y, B: int, IH: int, IW: int, OH: int, OW: int, relu: bool = False):
         self._launch(abi.lib.vdn_upsample_bilinear_f32, x.data_ptr(), y.data_ptr(), B, IH, IW, OH, OW, int(relu))
 
     def patchify(self, img, rows, B: int, H: int, W: int, ldk: int):
-        self._launch(abi.lib.vdn_patchify, self.dt, img.data_ptr(), rows.data_ptr(), B, H, W, ldk)
+        rows, rl = _hl(rows)
+        self._launch(abi.lib.vdn_patchify, self.dt, img.data_ptr(), rows.data_ptr(), rl, B, H, W, ldk)
 
     def fill_row(self, x, vec, B: int, rows_per_b: int, row: int, Cn: int):
         self._launch(abi.lib.vdn_fill_row, x.data_ptr(), vec.data_ptr(), B, rows_per_b, row, Cn)
@@ -189,7 +250,8 @@ class Runtime:
         self._launch(abi.lib.vdn_add_vec, x.data_ptr(), vec.data_ptr(), alpha, y.data_ptr(), rows, Cn)
 
     def head_out(self, feat, w, bias: float, depth, M: int, Cn: int, relu: bool):
-        self._launch(abi.lib.vdn_head_out, self.dt, feat.data_ptr(), w.data_ptr(), bias, depth.data_ptr(), M, Cn,
+        feat, fl = _hl(feat)
+        self._launch(abi.lib.vdn_head_out, self.dt, feat.data_ptr(), fl, w.data_ptr(), bias, depth.data_ptr(), M, Cn,
                      int(relu))
 
     def mask_down1(self, depth, out, B, H, W, OH, OW, w):
