@@ -92,12 +92,12 @@ class EncoderEngine:
         outs, last_f32 = [], None
         for i, b in enumerate(self.blocks):
             rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
-            rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads)
-            rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5)
-            rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok)
+            rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear")
+            rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn")
+            rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear")
             rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
-            rt.gemm(hn, b["wfc1"], M, 4 * C, C, bias=b["bfc1"], act=GELU, out=f1)
-            rt.gemm(f1, b["wfc2"], M, C, 4 * C, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok)
+            rt.gemm(hn, b["wfc1"], M, 4 * C, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
+            rt.gemm(f1, b["wfc2"], M, C, 4 * C, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
             if i in self.taps:
                 j = self.taps.index(i)
                 t = rt.hbuf(f"tap{j}", (Bf * P, C))

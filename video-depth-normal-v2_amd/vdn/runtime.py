@@ -82,6 +82,7 @@ class Runtime:
         self._plans: Dict[object, list] = {}
         self._rec: Optional[list] = None
         self._keep: List[object] = []
+        self.timing: Optional[list] = None  # bench.py: [(tag, start_event, end_event)] for tagged launches
 
     # ------------------------------------------------------------------ memory
     def buf(self, name: str, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
@@ -106,8 +107,16 @@ class Runtime:
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
     # ------------------------------------------------------------------ launch / record / replay
-    def _launch(self, fn, *args):
-        rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
+    def _launch(self, fn, *args, tag: Optional[str] = None):
+        if tag is not None and self.timing is not None:
+            # HIP events on the launch stream (torch's current stream is the stream the kernel runs on)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
+            e.record()
+            self.timing.append((tag, s, e))
+        else:
+            rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
         abi.check(rc, fn.__name__)
         if self._rec is not None:
             self._rec.append((fn, args))
@@ -143,7 +152,7 @@ class Runtime:
              out: Optional[torch.Tensor] = None, ldc: Optional[int] = None, bias=None, act: int = 0, gamma=None,
              rowadd=None, tab=None, tab_mod: int = 0, tab_off: int = 0, res1=None, ldr1=None, res2=None, ldr2=None,
              conv: Optional[dict] = None, relu_a: bool = False, store: int = abi.ST_PLAIN, row_group: int = 0,
-             row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None):
+             row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None, tag: Optional[str] = None):
         d = abi.GemmDesc()
         d.dt = self.dt
         d.M, d.N, d.K = M, N, K
@@ -197,7 +206,7 @@ class Runtime:
             d.ck, d.cout = convt["k"], convt["cout"]
             d.cB, d.cH, d.cW = convt["B"], convt["H"], convt["W"]
         d.zeros = self.zeros.data_ptr()
-        self._launch(abi.lib.vdn_gemm, C.byref(d))
+        self._launch(abi.lib.vdn_gemm, C.byref(d), tag=tag)
         self._keep_alive(d)
         return out
 
@@ -213,10 +222,11 @@ class Runtime:
                      self._p(addvec), alpha, self._p(addtab), tab_div, tab_mod, out_group, self._p(oh), ol, self.dt,
                      self._p(out_f))
 
-    def flash_attn(self, Q, K, Vt, out, B: int, H: int, nq: int, nq_pad: int, nk: int, nk_pad: int, scale: float):
+    def flash_attn(self, Q, K, Vt, out, B: int, H: int, nq: int, nq_pad: int, nk: int, nk_pad: int, scale: float,
+                   tag: Optional[str] = None):
         (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
         self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
-                     vl, ol, B, H, nq, nq_pad, nk, nk_pad, scale)
+                     vl, ol, B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag)
 
     def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
         (qkv, ql), (out, ol) = _hl(qkv), _hl(out)

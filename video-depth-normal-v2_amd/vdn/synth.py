@@ -98,11 +98,9 @@ def _fan_in(shape: Tuple[int, ...], key: str) -> int:
     return max(1, shape[-1])
 
 
-def synth_param(seed: int, key: str, shape: Tuple[int, ...]) -> np.ndarray:
-    shape = tuple(int(s) for s in shape)
-    z = normal(seed, key, shape)
+def _scale_rules(key: str, shape: Tuple[int, ...], z):
+    """Per-key scaling of a unit-normal tensor `z` (numpy array or torch tensor)."""
     leaf = key.split(".")[-1]
-    # ---- special tensors
     if leaf == "cls_token":
         return 0.5 * z
     if leaf == "pos_embed":
@@ -113,20 +111,17 @@ def synth_param(seed: int, key: str, shape: Tuple[int, ...]) -> np.ndarray:
         return 0.5 * z
     if leaf == "gamma":
         if ".fuser." in key:  # CXBlock layer scale (reference init 1e-6 would hide the block)
-            return (0.5 + 0.1 * z).astype(np.float32)
-        return (1.0 + 0.1 * z).astype(np.float32)  # ls1/ls2 (reference init_values=1.0)
-    is_norm = bool(re.search(r"(^|\.)(norm\d*|norms\.\d+|ff_norm|encoder\.1)\.(weight|bias)$", key)) or (
-        ".fuser." in key and ".norm." in key)
+            return 0.5 + 0.1 * z
+        return 1.0 + 0.1 * z  # ls1/ls2 (reference init_values=1.0)
+    is_norm = bool(re.search(r"(^|\.)(norm\d*|norms\.\d+|ff_norm|encoder\.1)\.(weight|bias)$", key))
     if is_norm:
-        if leaf == "weight":
-            return (1.0 + 0.1 * z).astype(np.float32)
-        return (0.05 * z).astype(np.float32)
+        return 1.0 + 0.1 * z if leaf == "weight" else 0.05 * z
     if leaf == "bias":
         if key.endswith("output_conv2.2.bias"):
-            return ((1.5 if key.startswith("head.") else 0.5) + 0.0 * z).astype(np.float32)
+            return (1.5 if key.startswith("head.") else 0.5) + 0.0 * z
         if key.endswith("output_conv2.0.bias"):
-            return (0.1 + 0.05 * z).astype(np.float32)
-        return (0.05 * z).astype(np.float32)
+            return 0.1 + 0.05 * z
+        return 0.05 * z
     if leaf == "weight":
         g = 1.0
         if ".attn.qkv." in key or key.endswith(("q_proj.weight", "k_proj.weight", "to_q.weight", "to_k.weight")):
@@ -136,12 +131,29 @@ def synth_param(seed: int, key: str, shape: Tuple[int, ...]) -> np.ndarray:
         if ".temporal_transformer.proj_out." in key:
             g = 0.5  # reference zero-inits this (motion_module.py:57-58); non-zero so the module is visible
         if key.endswith("output_conv2.2.weight"):
-            # zero-sum weights over the (non-negative, post-ReLU) inputs + bias 0.5:
-            # pre-ReLU depth ~ N(0.5, 0.4) — mostly positive, both signs present
+            # zero-sum weights over the (non-negative, post-ReLU) inputs + a positive bias:
+            # pre-ReLU depth mostly positive with both signs present
             z = z - z.mean()
             g = 0.6
-        return (z * (g / math.sqrt(_fan_in(shape, key)))).astype(np.float32)
-    return (0.1 * z).astype(np.float32)
+        return z * (g / math.sqrt(_fan_in(shape, key)))
+    return 0.1 * z
+
+
+def synth_param(seed: int, key: str, shape: Tuple[int, ...]) -> np.ndarray:
+    shape = tuple(int(s) for s in shape)
+    return np.asarray(_scale_rules(key, shape, normal(seed, key, shape)), dtype=np.float32)
+
+
+def fast_state_dict(named_shapes, seed: int = 1234):
+    """Same scale rules, torch's generator instead of the portable counter hash: seconds instead of
+    a minute for ViT-L. Used where only timing matters (bench.py); NOT what the fixtures pin."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, shp in named_shapes:
+        shp = tuple(int(v) for v in shp)
+        out[k] = _scale_rules(k, shp, torch.randn(shp, generator=g)).float().contiguous()
+    return out
 
 
 def synth_state_dict(named_shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 1234) -> Dict[str, np.ndarray]:
