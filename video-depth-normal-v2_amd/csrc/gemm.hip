@@ -19,159 +19,16 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int DT, int BM, int BN, int WM, int WN, int AMODE /*0 plain,1 conv,2 conv+relu,3 plain+relu*/>
-__global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
+// Epilogue shared by both main loops: accumulators -> LDS (fp32 tile) -> fused fp32 math -> wide
+// row stores. Must be entered after a barrier (the staging buffers are reused for the tile).
+template <int DT, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const vdn_gemm_desc& p,
+                                              char* smem, int m0, int n0, int tid, int lane, int wave) {
   using H = Half<DT>;
-  using V8 = typename H::V8;
   using T = typename H::T;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
-  constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 1-KiB DMA pieces per wave and operand
-  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
-  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-
-  // ---- staging geometry (fixed per lane over the whole K loop)
-  const int lr = lane >> 3;                                   // row inside an 8-row DMA piece
-  const int chunk = (lane & 7) ^ ((((wave & 1) << 2) + (lr >> 1)) & 7);  // source 16-B chunk
-  const T* a_row[A_IT];
-  int a_iy[A_IT], a_ix[A_IT];
-  const T* A = (const T*)p.A;
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + (i * 4 + wave) * 8 + lr;
-    m = m < p.M ? m : p.M - 1;
-    if constexpr (CONV) {
-      const int hw = p.cOH * p.cOW;
-      const int b = m / hw, rem = m - b * hw;
-      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
-      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
-      a_iy[i] = oy * p.cstride - 1;
-      a_ix[i] = ox * p.cstride - 1;
-    } else {
-      a_row[i] = A + (size_t)m * p.lda;
-      a_iy[i] = a_ix[i] = 0;
-    }
-  }
-  const T* b_row[B_IT];
-#pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    int n = n0 + (i * 4 + wave) * 8 + lr;
-    n = n < p.N ? n : p.N - 1;
-    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
-  }
-  const T* zeros = (const T*)p.zeros;
-  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
-
-  // K segments: [A_hi x W_hi] (+ [A_hi x W_lo]) (+ [A_lo x W_hi]) — the split-precision planes are
-  // just further stretches of the same accumulation loop, selected by a plane byte offset.
-  const int nk1 = p.ldb / BK;
-  const int seg_wlo = p.W_lo ? 1 : -1;
-  const int nseg = 1 + (p.W_lo ? 1 : 0) + (p.A_lo ? 1 : 0);
-  const int seg_alo = p.A_lo ? nseg - 1 : -1;
-  const ptrdiff_t a_delta = p.A_lo ? (const char*)p.A_lo - (const char*)p.A : 0;
-  const ptrdiff_t w_delta = p.W_lo ? (const char*)p.W_lo - (const char*)p.W : 0;
-
-  auto stage = [&](int buf, int kt_all) {
-    char* sA = smem + buf * STAGE;
-    char* sB = sA + A_BYTES;
-    const int seg = kt_all / nk1;
-    const int kt = kt_all - seg * nk1;
-    const ptrdiff_t ad = (seg == seg_alo) ? a_delta : 0;
-    const ptrdiff_t wd = (seg == seg_wlo) ? w_delta : 0;
-    const int k = kt * BK + chunk * 8;
-    if constexpr (CONV) {
-      // (tap, ci) of this lane's chunk; Cin % 8 == 0 so a chunk never straddles two taps
-      const int kc = k >> 3;
-      const int tap = (int)(((float)kc + 0.5f) * inv_cin);
-      const int ci = k - tap * p.cC;
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-        const bool ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
-        const char* src = ok ? (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci) + ad : (const char*)zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
-                                         16, 0, 0);
-      }
-    } else {
-      const bool ok = k < p.K;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const char* src = ok ? (const char*)(a_row[i] + k) + ad : (const char*)zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
-                                         16, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const char* src = (const char*)(b_row[i] + k) + wd;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sB + (i * 4 + wave) * 1024),
-                                       16, 0, 0);
-    }
-  };
-
-  // ---- fragment read geometry
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
-  int a_off[TM][2], b_off[TN][2];
-#pragma unroll
-  for (int t = 0; t < TM; ++t) {
-    const int row = wm * WTM + t * 16 + fr;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) a_off[t][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
-  }
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int row = wn * WTN + t * 16 + fr;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) b_off[t][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
-  }
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = nk1 * nseg;
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sA = smem + cur * STAGE;
-    const char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      V8 af[TM], bf[TN];
-#pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        af[t] = *(const V8*)(sA + a_off[t][kk]);
-        if constexpr (RELU_A) af[t] = relu8(af[t]);
-      }
-#pragma unroll
-      for (int t = 0; t < TN; ++t) bf[t] = *(const V8*)(sB + b_off[t][kk]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = H::mfma16(af[i], bf[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: accumulators -> LDS (fp32 tile) -> fused fp32 math -> wide row stores.
-  // The K loop ended with a barrier, so the staging buffers are free to be reused.
   constexpr int LDT = BN + 4;  // padded fp32 row (floats)
   float* tileC = (float*)smem;
 #pragma unroll
@@ -343,6 +200,307 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
   }
 }
 
+template <int DT, int BM, int BN, int WM, int WN, int AMODE /*0 plain,1 conv,2 conv+relu,3 plain+relu*/>
+__global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 1-KiB DMA pieces per wave and operand
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  // ---- staging geometry (fixed per lane over the whole K loop)
+  const int lr = lane >> 3;                                   // row inside an 8-row DMA piece
+  const int chunk = (lane & 7) ^ ((((wave & 1) << 2) + (lr >> 1)) & 7);  // source 16-B chunk
+  const T* a_row[A_IT];
+  int a_iy[A_IT], a_ix[A_IT];
+  const T* A = (const T*)p.A;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + (i * 4 + wave) * 8 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const T* b_row[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    int n = n0 + (i * 4 + wave) * 8 + lr;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
+  }
+  const T* zeros = (const T*)p.zeros;
+  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+
+  // K segments: [A_hi x W_hi] (+ [A_hi x W_lo]) (+ [A_lo x W_hi]) — the split-precision planes are
+  // just further stretches of the same accumulation loop, selected by a plane byte offset.
+  const int nk1 = p.ldb / BK;
+  const int seg_wlo = p.W_lo ? 1 : -1;
+  const int nseg = 1 + (p.W_lo ? 1 : 0) + (p.A_lo ? 1 : 0);
+  const int seg_alo = p.A_lo ? nseg - 1 : -1;
+  const ptrdiff_t a_delta = p.A_lo ? (const char*)p.A_lo - (const char*)p.A : 0;
+  const ptrdiff_t w_delta = p.W_lo ? (const char*)p.W_lo - (const char*)p.W : 0;
+
+  auto stage = [&](int buf, int kt_all) {
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
+    const int seg = kt_all / nk1;
+    const int kt = kt_all - seg * nk1;
+    const ptrdiff_t ad = (seg == seg_alo) ? a_delta : 0;
+    const ptrdiff_t wd = (seg == seg_wlo) ? w_delta : 0;
+    const int k = kt * BK + chunk * 8;
+    if constexpr (CONV) {
+      // (tap, ci) of this lane's chunk; Cin % 8 == 0 so a chunk never straddles two taps
+      const int kc = k >> 3;
+      const int tap = (int)(((float)kc + 0.5f) * inv_cin);
+      const int ci = k - tap * p.cC;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+        const char* src = ok ? (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci) + ad : (const char*)zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
+                                         16, 0, 0);
+      }
+    } else {
+      const bool ok = k < p.K;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const char* src = ok ? (const char*)(a_row[i] + k) + ad : (const char*)zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
+                                         16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const char* src = (const char*)(b_row[i] + k) + wd;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sB + (i * 4 + wave) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  // ---- fragment read geometry
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_off[t][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_off[t][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = nk1 * nseg;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sA = smem + cur * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      V8 af[TM], bf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        af[t] = *(const V8*)(sA + a_off[t][kk]);
+        if constexpr (RELU_A) af[t] = relu8(af[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[t] = *(const V8*)(sB + b_off[t][kk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = H::mfma16(af[i], bf[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue<DT, BM, BN, WM, WN>(acc, p, smem, m0, n0, tid, lane, wave);
+}
+
+// Split-precision main loop with the planes FUSED per K step (BK = 32): one stage holds
+// A_hi, A_lo, W_hi, W_lo tiles; every fragment is read from LDS once and feeds
+// hi*hi + hi*lo + lo*hi, i.e. 16 ds_read_b128 per 48 MFMAs (vs 16 per 32 in the 1-product loop) and
+// 1.5x more MFMA work per barrier. 64-byte LDS rows, swizzle chunk ^ ((-(row>>2)) & 3) keeps the
+// ds_read_b128 lane groups {0-3,12-15,20-27}.. on 16 distinct 16-byte slots.
+template <int DT, int AMODE /*0 plain,1 conv,2 conv+relu,3 plain+relu*/>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, BK3 = 32;
+  constexpr int TILE = 128 * BK3 * 2;           // 8 KiB per operand plane
+  constexpr int STAGE = 4 * TILE;               // A_hi | A_lo | W_hi | W_lo
+  constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  // staging: a 1-KiB DMA piece = 16 rows x 64 B; each wave moves pieces 2w, 2w+1 of every plane
+  const int lr = lane >> 2;                                   // row inside the piece
+  const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);     // source 16-B chunk (row>>2 == lane>>4 mod 4)
+  const T* a_row[2];
+  int a_iy[2], a_ix[2];
+  const T* A = (const T*)p.A;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + (wave * 2 + i) * 16 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const T* b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int n = n0 + (wave * 2 + i) * 16 + lr;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
+  }
+  const char* zeros = (const char*)p.zeros;
+  const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
+  const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
+  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+
+#define VDN_GLDS(src, dst)                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+  auto stage = [&](int buf, int kt) {
+    char* s0 = smem + buf * STAGE;
+    const int k = kt * BK3 + chunk * 8;
+    int ky = 0, kx = 0, ci = 0;
+    bool kok = k < p.K;
+    if constexpr (CONV) {
+      const int tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
+      ci = k - tap * p.cC;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+      kok = tap < 9;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave * 2 + i;
+      const char* src;
+      bool ok = kok;
+      if constexpr (CONV) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+        src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+      } else {
+        src = (const char*)(a_row[i] + k);
+      }
+      VDN_GLDS(ok ? src : zeros, s0 + pc * 1024);
+      VDN_GLDS(ok ? src + a_delta : zeros, s0 + TILE + pc * 1024);
+      const char* ws = (const char*)(b_row[i] + k);
+      VDN_GLDS(ws, s0 + 2 * TILE + pc * 1024);
+      VDN_GLDS(ws + w_delta, s0 + 3 * TILE + pc * 1024);
+    }
+  };
+#undef VDN_GLDS
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TM], b_off[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 16 + fr;
+    a_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * 16 + fr;
+    b_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.ldb / BK3;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* s0 = smem + cur * STAGE;
+    V8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      ah[t] = *(const V8*)(s0 + a_off[t]);
+      al[t] = *(const V8*)(s0 + TILE + a_off[t]);
+      if constexpr (RELU_A) { ah[t] = relu8(ah[t]); al[t] = relu8(al[t]); }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      bh[t] = *(const V8*)(s0 + 2 * TILE + b_off[t]);
+      bl[t] = *(const V8*)(s0 + 3 * TILE + b_off[t]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = H::mfma16(al[i], bh[j], acc[i][j]);
+        acc[i][j] = H::mfma16(ah[i], bl[j], acc[i][j]);
+        acc[i][j] = H::mfma16(ah[i], bh[j], acc[i][j]);
+      }
+    __syncthreads();
+  }
+  gemm_epilogue<DT, BM, BN, WM, WN>(acc, p, smem, m0, n0, tid, lane, wave);
+}
+
 template <int DT, int BM, int BN, int WM, int WN>
 int launch_tile(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
@@ -361,7 +519,24 @@ int launch_tile(const vdn_gemm_desc& d, hipStream_t s) {
 }
 
 template <int DT>
+int launch_x3(const vdn_gemm_desc& d, hipStream_t s) {
+  const int tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128);
+  const size_t lds = 128 * 132 * 4;  // max(2 stages x 32 KiB, fp32 epilogue tile)
+  const bool conv = d.a_mode == VDN_A_CONV3X3;
+  const int amode = conv ? (d.relu_a ? 2 : 1) : (d.relu_a ? 3 : 0);
+  switch (amode) {
+    case 0: hipLaunchKernelGGL((gemm_x3_kernel<DT, 0>), dim3(tiles), dim3(256), lds, s, d); break;
+    case 1: hipLaunchKernelGGL((gemm_x3_kernel<DT, 1>), dim3(tiles), dim3(256), lds, s, d); break;
+    case 2: hipLaunchKernelGGL((gemm_x3_kernel<DT, 2>), dim3(tiles), dim3(256), lds, s, d); break;
+    default: hipLaunchKernelGGL((gemm_x3_kernel<DT, 3>), dim3(tiles), dim3(256), lds, s, d); break;
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+template <int DT>
 int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
+  if (d.A_lo && d.W_lo && (d.store == VDN_ST_HEADS || d.N > 64)) return launch_x3<DT>(d, s);
   if (d.store == VDN_ST_HEADS || d.N > 64) return launch_tile<DT, 128, 128, 2, 2>(d, s);
   if (d.N > 32) return launch_tile<DT, 128, 64, 2, 2>(d, s);
   return launch_tile<DT, 128, 32, 4, 1>(d, s);
