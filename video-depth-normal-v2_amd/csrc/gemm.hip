@@ -14,37 +14,25 @@
 //
 // Roofline: MFMA-bound (>= 170 flop per HBM byte on every shape of the path).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;
 
-// Epilogue shared by both main loops: accumulators -> LDS (fp32 tile) -> fused fp32 math -> wide
-// row stores. Must be entered after a barrier (the staging buffers are reused for the tile).
-template <int DT, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const vdn_gemm_desc& p,
-                                              char* smem, int m0, int n0, int tid, int lane, int wave) {
+// Fused fp32 epilogue over a ROWS x BN fp32 tile held in LDS (row stride BN + 4 floats):
+// bias / row-add / activation / LayerScale / pos-embed table / residuals, then wide stores in the
+// layout the consumer reads (plain rows, per-head Q/K/V^T with RoPE, pixel-shuffle, GEGLU).
+template <int DT, int ROWS, int BN, int NT>
+__device__ __forceinline__ void epilogue_tile(const vdn_gemm_desc& p, const float* tileC, int mbase, int n0, int tid) {
   using H = Half<DT>;
   using T = typename H::T;
-  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
-  const int wm = wave / WN, wn = wave % WN;
-  const int fr = lane & 15, fq = lane >> 4;
-  constexpr int LDT = BN + 4;  // padded fp32 row (floats)
-  float* tileC = (float*)smem;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        tileC[(wm * WTM + i * 16 + fq * 4 + j) * LDT + wn * WTN + t * 16 + fr] = acc[i][t][j];
-  __syncthreads();
-
+  constexpr int LDT = BN + 4;
   constexpr int CG = BN / 4;  // 4-column groups per tile row
   if (p.store == VDN_ST_PLAIN || p.store == VDN_ST_CONVT) {
-    for (int idx = tid; idx < BM * CG; idx += 256) {
+    for (int idx = tid; idx < ROWS * CG; idx += NT) {
       const int r = idx / CG, c = (idx - r * CG) * 4;
-      const int m = m0 + r, n = n0 + c;
+      const int m = mbase + r, n = n0 + c;
       if (m >= p.M || n >= p.N) continue;
       const f32x4 a = *(const f32x4*)(tileC + r * LDT + c);
       float v[4] = {a[0], a[1], a[2], a[3]};
@@ -92,10 +80,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
     }
   } else if (p.store == VDN_ST_GEGLU) {
     // packed columns: 16-wide blocks alternate [h | gate]; output column nc <- (h, gate) pair
-    for (int idx = tid; idx < BM * (CG / 2); idx += 256) {
+    for (int idx = tid; idx < ROWS * (CG / 2); idx += NT) {
       const int r = idx / (CG / 2), oc = (idx - r * (CG / 2)) * 4;  // output column inside the tile
       const int ch = (oc >> 4) * 32 + (oc & 15);                     // packed h column inside the tile
-      const int m = m0 + r;
+      const int m = mbase + r;
       if (m >= p.M || n0 + ch + 16 >= p.N) continue;
       const f32x4 hh = *(const f32x4*)(tileC + r * LDT + ch);
       const f32x4 gg = *(const f32x4*)(tileC + r * LDT + ch + 16);
@@ -123,9 +111,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
   } else {  // VDN_ST_HEADS
     const int hc = p.heads * 64;
     // pass 1: token-major splits, one thread = 4 columns (plain) or 4 rotated pairs (RoPE)
-    for (int idx = tid; idx < BM * CG; idx += 256) {
+    for (int idx = tid; idx < ROWS * CG; idx += NT) {
       const int r = idx / CG, c = (idx - r * CG) * 4;
-      const int m = m0 + r, n = n0 + c;
+      const int m = mbase + r, n = n0 + c;
       if (m >= p.M || n >= p.N) continue;
       const int split = n / hc;
       if (p.transposed[split]) continue;
@@ -176,8 +164,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
     bool any_t = false;
     for (int i = 0; i < p.nsplit; ++i) any_t |= (p.transposed[i] != 0);
     if (any_t) {
-      constexpr int RG = BM / 4;
-      for (int idx = tid; idx < BN * RG; idx += 256) {
+      constexpr int RG = ROWS / 4;
+      for (int idx = tid; idx < BN * RG; idx += NT) {
         const int c = idx / RG, r = (idx - c * RG) * 4;
         const int n = n0 + c;
         if (n >= p.N) continue;
@@ -189,7 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
         T* dlo = (T*)p.dst_lo[split];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int m = m0 + r + k;
+          const int m = mbase + r + k;
           if (m >= p.M) break;
           const int bt = m / p.tokens, tl = m - bt * p.tokens;
           store_half(dst, dlo, (((size_t)bt * p.heads + head) * 64 + e) * p.tpad + tl + p.tok_off,
@@ -198,6 +186,27 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN
       }
     }
   }
+}
+
+// 4-wave kernels: accumulators -> LDS, then the shared epilogue. Must be entered after a barrier
+// (the staging buffers are reused for the tile).
+template <int DT, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const vdn_gemm_desc& p,
+                                              char* smem, int m0, int n0, int tid, int lane, int wave) {
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  constexpr int LDT = BN + 4;  // padded fp32 row (floats)
+  float* tileC = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        tileC[(wm * WTM + i * 16 + fq * 4 + j) * LDT + wn * WTN + t * 16 + fr] = acc[i][t][j];
+  __syncthreads();
+  epilogue_tile<DT, BM, BN, 256>(p, tileC, m0, n0, tid);
 }
 
 template <int DT, int BM, int BN, int WM, int WN, int AMODE /*0 plain,1 conv,2 conv+relu,3 plain+relu*/>
@@ -501,6 +510,197 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
   gemm_epilogue<DT, BM, BN, WM, WN>(acc, p, smem, m0, n0, tid, lane, wave);
 }
 
+// Large-tile split-precision main loop: BM x 256 x 32, 8 waves (2 x 4, wave tile BM/2 x 64), one
+// workgroup per CU. Per K step a CU moves (BM + 256) * 128 B into LDS for BM*256*32*3 MACs:
+// 150-200 flop per byte, which is what the ~25 B/clk/CU global->LDS path can feed (the 128 x 128
+// tile needs 43 B/clk at full MFMA rate and stalls on it — profiles/r01_*).
+// BM in {128, 192, 256} is chosen per launch so that the tile count fills the 256 CUs evenly.
+template <int DT, int AMODE, int BM>
+__global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  constexpr int BN = 256, BK3 = 32;
+  constexpr int A_TILE = BM * 64, W_TILE = BN * 64;      // bytes per plane
+  constexpr int STAGE = 2 * A_TILE + 2 * W_TILE;         // A_hi | A_lo | W_hi | W_lo
+  constexpr int TMW = BM / 32, TNW = 4, HALF = TMW / 2;  // frags per wave, A processed in two halves
+  constexpr int AP = BM / 16, WP = BN / 16;              // 1-KiB pieces per plane
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  // tile order inside an XCD's run: groups of 4 m-tiles walk n first, so that the ~32 tiles an
+  // XCD has in flight share A rows 8-fold and W columns 4-fold through its L2
+  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm_i, tn_i;
+  {
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int g = tile / per_group, r = tile - g * per_group;
+    const int gm = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tn_i = r / gm;
+    tm_i = g * GM + (r - tn_i * gm);
+  }
+  const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+  const int lr = lane >> 2;
+  const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+  const T* A = (const T*)p.A;
+  const T* a_row[2];
+  int a_iy[2], a_ix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pc = wave + 8 * i;
+    int m = m0 + pc * 16 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const T* b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int n = n0 + (wave + 8 * i) * 16 + lr;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
+  }
+  const char* zeros = (const char*)p.zeros;
+  const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
+  const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
+  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+
+#define VDN_GLDS(src, dst)                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+  auto stage = [&](int buf, int kt) {
+    char* s0 = smem + buf * STAGE;
+    const int k = kt * BK3 + chunk * 8;
+    int ky = 0, kx = 0, ci = 0;
+    bool kok = k < p.K;
+    if constexpr (CONV) {
+      const int tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
+      ci = k - tap * p.cC;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+      kok = tap < 9;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < AP) {
+        const char* src;
+        bool ok = kok;
+        if constexpr (CONV) {
+          const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+          ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+          src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+        } else {
+          src = (const char*)(a_row[i] + k);
+        }
+        VDN_GLDS(ok ? src : zeros, s0 + pc * 1024);
+        VDN_GLDS(ok ? src + a_delta : zeros, s0 + A_TILE + pc * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i;
+      const char* ws = (const char*)(b_row[i] + k);
+      VDN_GLDS(ws, s0 + 2 * A_TILE + pc * 1024);
+      VDN_GLDS(ws + w_delta, s0 + 2 * A_TILE + W_TILE + pc * 1024);
+    }
+  };
+#undef VDN_GLDS
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TMW], b_off[TNW];
+#pragma unroll
+  for (int t = 0; t < TMW; ++t) {
+    const int row = wm * (BM / 2) + t * 16 + fr;
+    a_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TNW; ++t) {
+    const int row = wn * 64 + t * 16 + fr;
+    b_off[t] = 2 * A_TILE + row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[TMW][TNW];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.ldb / BK3;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* s0 = smem + cur * STAGE;
+    V8 bh[TNW], bl[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+      bh[t] = *(const V8*)(s0 + b_off[t]);
+      bl[t] = *(const V8*)(s0 + W_TILE + b_off[t]);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      V8 ah[HALF], al[HALF];
+#pragma unroll
+      for (int t = 0; t < HALF; ++t) {
+        ah[t] = *(const V8*)(s0 + a_off[hf * HALF + t]);
+        al[t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
+        if constexpr (RELU_A) { ah[t] = relu8(ah[t]); al[t] = relu8(al[t]); }
+      }
+#pragma unroll
+      for (int i = 0; i < HALF; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          f32x4 c = acc[hf * HALF + i][j];
+          c = H::mfma16(al[i], bh[j], c);
+          c = H::mfma16(ah[i], bl[j], c);
+          c = H::mfma16(ah[i], bh[j], c);
+          acc[hf * HALF + i][j] = c;
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue in 64-row passes through a [64][BN + 4] fp32 LDS tile
+  constexpr int LDT = BN + 4;
+  float* tileC = (float*)smem;
+#pragma unroll
+  for (int pass = 0; pass < BM / 64; ++pass) {
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) {
+      const int row0 = wm * (BM / 2) + t * 16;  // wave-uniform
+      if (row0 / 64 == pass) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            tileC[(row0 - pass * 64 + fq * 4 + e) * LDT + wn * 64 + j * 16 + fr] = acc[t][j][e];
+      }
+    }
+    __syncthreads();
+    epilogue_tile<DT, 64, BN, 512>(p, tileC, m0 + pass * 64, n0, tid);
+    __syncthreads();
+  }
+}
+
 template <int DT, int BM, int BN, int WM, int WN>
 int launch_tile(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
@@ -534,8 +734,45 @@ int launch_x3(const vdn_gemm_desc& d, hipStream_t s) {
   return VDN_OK;
 }
 
+template <int DT, int BM>
+int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + 255) / 256);
+  const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * 256 * 64);
+  const bool conv = d.a_mode == VDN_A_CONV3X3;
+  const int amode = conv ? (d.relu_a ? 2 : 1) : (d.relu_a ? 3 : 0);
+  switch (amode) {
+    case 0: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM>), dim3(tiles), dim3(512), lds, s, d); break;
+    case 1: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 1, BM>), dim3(tiles), dim3(512), lds, s, d); break;
+    case 2: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, BM>), dim3(tiles), dim3(512), lds, s, d); break;
+    default: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 3, BM>), dim3(tiles), dim3(512), lds, s, d); break;
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+// Pick the M tile that wastes the fewest CU-rounds: cost = rounds(256 CUs) * BM, padded work included.
+inline int pick_bm(int M, int N) {
+  const int tn = (N + 255) / 256;
+  int best = 0;
+  double best_cost = 1e30;
+  for (int bm : {256, 192, 128}) {
+    const long tiles = (long)((M + bm - 1) / bm) * tn;
+    const long rounds = (tiles + 255) / 256;
+    const double cost = (double)rounds * bm * (bm == 128 ? 1.12 : (bm == 192 ? 1.04 : 1.0));  // smaller tiles feed worse
+    if (cost < best_cost) { best_cost = cost; best = bm; }
+  }
+  return best;
+}
+
 template <int DT>
 int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
+  if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024) {
+    const char* force = getenv("VDN_GEMM_BM");
+    const int bm = force ? atoi(force) : pick_bm(d.M, d.N);
+    if (bm == 256) return launch_x3_big<DT, 256>(d, s);
+    if (bm == 192) return launch_x3_big<DT, 192>(d, s);
+    if (bm == 128) return launch_x3_big<DT, 128>(d, s);
+  }
   if (d.A_lo && d.W_lo && (d.store == VDN_ST_HEADS || d.N > 64)) return launch_x3<DT>(d, s);
   if (d.store == VDN_ST_HEADS || d.N > 64) return launch_tile<DT, 128, 128, 2, 2>(d, s);
   if (d.N > 32) return launch_tile<DT, 128, 64, 2, 2>(d, s);
