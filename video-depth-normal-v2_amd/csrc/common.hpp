@@ -67,6 +67,33 @@ __device__ __forceinline__ float gelu_erf(float x) {  // nn.GELU() default (exac
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// Exact-form GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32-level):
+// ~15 VALU ops instead of libm erff's ~40 — the GEMM epilogue applies it to every fc1 output.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erf_abs = fmaf(-poly, e, 1.0f);          // erf(|x|/sqrt2)
+  const float erf_s = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erf_s);
+}
+
+// 4 consecutive values of a residual / table operand as floats (16-byte or 8-byte vector load)
+__device__ __forceinline__ f32x4 load4_as_float(const void* p, int dt, size_t i) {
+  if (dt == VDN_F32) return *(const f32x4*)((const float*)p + i);
+  if (dt == VDN_F16) {
+    const f16x4 h = *(const f16x4*)((const _Float16*)p + i);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+  const bf16x4 h = *(const bf16x4*)((const __bf16*)p + i);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
 __device__ __forceinline__ float load_as_float(const void* p, int dt, size_t i) {
   if (dt == VDN_F32) return ((const float*)p)[i];
   if (dt == VDN_F16) return (float)((const _Float16*)p)[i];

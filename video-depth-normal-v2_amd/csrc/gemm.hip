@@ -34,26 +34,27 @@ __device__ __forceinline__ void epilogue_tile(const vdn_gemm_desc& p, const floa
       const int r = idx / CG, c = (idx - r * CG) * 4;
       const int m = mbase + r, n = n0 + c;
       if (m >= p.M || n >= p.N) continue;
-      const f32x4 a = *(const f32x4*)(tileC + r * LDT + c);
-      float v[4] = {a[0], a[1], a[2], a[3]};
-      const float radd = p.rowadd ? p.rowadd[m] : 0.f;
+      f32x4 a = *(const f32x4*)(tileC + r * LDT + c);
+      if (p.bias) a += *(const f32x4*)(p.bias + n);
+      if (p.rowadd) a += p.rowadd[m];
+      if (p.act == VDN_ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (p.bias) v[e] += p.bias[n + e];
-        v[e] += radd;
-        if (p.act == VDN_ACT_GELU) v[e] = gelu_erf(v[e]);
-        else if (p.act == VDN_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-        if (p.gamma) v[e] *= p.gamma[n + e];
-        if (p.tab) v[e] += p.tab[(size_t)(m % p.tab_mod + p.tab_off) * p.N + n + e];
-        if (p.res1) {
-          v[e] += load_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n + e);
-          if (p.res1_lo) v[e] += load_as_float(p.res1_lo, p.res1_dt, (size_t)m * p.ldr1 + n + e);
-        }
-        if (p.res2) {
-          v[e] += load_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n + e);
-          if (p.res2_lo) v[e] += load_as_float(p.res2_lo, p.res2_dt, (size_t)m * p.ldr2 + n + e);
-        }
+        for (int e = 0; e < 4; ++e) a[e] = gelu_fast(a[e]);
+      } else if (p.act == VDN_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
       }
+      if (p.gamma) a *= *(const f32x4*)(p.gamma + n);
+      if (p.tab) a += *(const f32x4*)(p.tab + (size_t)(m % p.tab_mod + p.tab_off) * p.N + n);
+      if (p.res1) {
+        a += load4_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n);
+        if (p.res1_lo) a += load4_as_float(p.res1_lo, p.res1_dt, (size_t)m * p.ldr1 + n);
+      }
+      if (p.res2) {
+        a += load4_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n);
+        if (p.res2_lo) a += load4_as_float(p.res2_lo, p.res2_dt, (size_t)m * p.ldr2 + n);
+      }
+      const float v[4] = {a[0], a[1], a[2], a[3]};
       size_t o;
       if (p.store == VDN_ST_CONVT) {
         const int hw = p.cH * p.cW;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void epilogue_tile(const vdn_gemm_desc& p, const floa
       for (int e = 0; e < 4; ++e) {
         const float hv = hh[e] + (p.bias ? p.bias[n0 + ch + e] : 0.f);
         const float gv = gg[e] + (p.bias ? p.bias[n0 + ch + 16 + e] : 0.f);
-        v[e] = hv * gelu_erf(gv);
+        v[e] = hv * gelu_fast(gv);
       }
       const size_t o = (size_t)m * p.ldc + (n0 >> 1) + oc;
       if (p.out_dt == VDN_F32) {
@@ -621,6 +622,33 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
       VDN_GLDS(ws + w_delta, s0 + 2 * A_TILE + W_TILE + pc * 1024);
     }
   };
+  // plain rows: per-lane source pointers advance by 64 B per K step (no per-step address math)
+  const char* ap[2][2];
+  const char* wp[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ap[i][0] = (const char*)(a_row[i] + chunk * 8);
+    ap[i][1] = ap[i][0] + a_delta;
+    wp[i][0] = (const char*)(b_row[i] + chunk * 8);
+    wp[i][1] = wp[i][0] + w_delta;
+  }
+  auto stage_plain = [&](int buf) {
+    char* s0 = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < AP) {
+        VDN_GLDS(ap[i][0], s0 + pc * 1024);
+        VDN_GLDS(ap[i][1], s0 + A_TILE + pc * 1024);
+        ap[i][0] += 64;
+        ap[i][1] += 64;
+      }
+      VDN_GLDS(wp[i][0], s0 + 2 * A_TILE + pc * 1024);
+      VDN_GLDS(wp[i][1], s0 + 2 * A_TILE + W_TILE + pc * 1024);
+      wp[i][0] += 64;
+      wp[i][1] += 64;
+    }
+  };
 #undef VDN_GLDS
 
   const int wm = wave >> 2, wn = wave & 3;
@@ -644,11 +672,13 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
     for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.ldb / BK3;
-  stage(0, 0);
+  if constexpr (CONV) stage(0, 0); else stage_plain(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    if (kt + 1 < nk) {
+      if constexpr (CONV) stage(cur ^ 1, kt + 1); else stage_plain(cur ^ 1);
+    }
     const char* s0 = smem + cur * STAGE;
     V8 bh[TNW], bl[TNW];
 #pragma unroll
@@ -766,7 +796,8 @@ inline int pick_bm(int M, int N) {
 
 template <int DT>
 int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
-  if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024) {
+  if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024 &&
+      (d.a_mode == VDN_A_CONV3X3 || (d.K & 31) == 0)) {
     const char* force = getenv("VDN_GEMM_BM");
     const int bm = force ? atoi(force) : pick_bm(d.M, d.N);
     if (bm == 256) return launch_x3_big<DT, 256>(d, s);
@@ -800,6 +831,8 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if (d.N & 3) return VDN_EALIGN;  // the epilogue stores 4 columns per lane
   if (((uintptr_t)d.A_lo | (uintptr_t)d.W_lo | (uintptr_t)d.out_lo) & 15) return VDN_EALIGN;
   if (d.out_lo && (d.out_dt == VDN_F32 || !d.out)) return VDN_EINVAL;
+  if ((d.res1 && (d.ldr1 & 3)) || (d.res2 && (d.ldr2 & 3))) return VDN_EALIGN;
+  if (((uintptr_t)d.bias | (uintptr_t)d.gamma | (uintptr_t)d.tab | (uintptr_t)d.res1 | (uintptr_t)d.res2) & 7) return VDN_EALIGN;
   switch (d.store) {
     case VDN_ST_PLAIN:
       if (!d.out || d.ldc < d.N) return VDN_EINVAL;
