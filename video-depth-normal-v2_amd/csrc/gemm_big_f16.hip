@@ -1,0 +1,9 @@
+// 8-wave BM x 256 split-precision GEMM kernels for f16 operands.
+#include "gemm_kernels.hpp"
+namespace vdn_gemm_impl {
+template <> int big_entry<VDN_F16>(const vdn_gemm_desc& d, int bm, hipStream_t s) {
+  if (bm == 256) return launch_x3_big<VDN_F16, 256>(d, s);
+  if (bm == 192) return launch_x3_big<VDN_F16, 192>(d, s);
+  return launch_x3_big<VDN_F16, 128>(d, s);
+}
+}

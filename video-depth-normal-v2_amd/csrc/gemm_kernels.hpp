@@ -1,0 +1,784 @@
+// GEMM / implicit-GEMM convolution for gfx950:  out = epilogue(A[M,K] x W[N,K]^T)
+//
+// * half (fp16|bf16) operands, fp32 accumulate on v_mfma_f32_16x16x32_{f16,bf16}
+// * BM x BN x 64 tiles, 4 waves (WM x WN), both operands staged global -> LDS by LDS-DMA
+//   (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave-instruction) into a double buffer;
+//   the LDS image is lane-linear, the bank-conflict swizzle (16-B chunk ^ ((row>>1)&7) on 128-B
+//   rows) is applied on the per-lane SOURCE address and again on the ds_read_b128 address
+//   (guide §5.4 rule 21)
+// * the A row can be a plain row-major row or an on-the-fly 3x3 (stride 1|2, pad 1) NHWC gather:
+//   the per-lane source pointer makes the DMA itself the im2col; padding taps read a zero page
+// * everything the reference does around its Linear/Conv (bias, GELU/ReLU, LayerScale, pos-embed,
+//   residual adds, head split + RoPE, pixel-shuffle for ConvTranspose, GEGLU) happens on the
+//   fp32 accumulators before the single store.
+//
+// Roofline: MFMA-bound (>= 170 flop per HBM byte on every shape of the path).
+#pragma once
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace vdn_gemm_impl {
+
+constexpr int BK = 64;
+
+// Fused fp32 epilogue straight from the accumulators. The MFMAs are issued with the WEIGHT fragment
+// as the A operand and the activation fragment as B, so the accumulator tile is C^T:
+//   acc[i][j][e]  ->  C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + 4 (lane >> 4) + e]
+// i.e. every lane owns 4 CONSECUTIVE output columns of one row: bias / gamma / table / residual
+// operands are single 16-byte loads and the result leaves as one 8- or 16-byte store per plane,
+// with no LDS round trip and no barrier (all 8 waves work on their own tile in parallel).
+// STORE is the vdn_store mode (compile-time in the big kernel, dispatched at run time elsewhere).
+template <int DT, int TM, int TN, int STORE>
+__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
+  using H = Half<DT>;
+  using T = typename H::T;
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mw + i * 16 + fr;
+    if (m >= p.M) continue;
+    if constexpr (STORE == VDN_ST_PLAIN || STORE == VDN_ST_CONVT) {
+      const float radd = p.rowadd ? p.rowadd[m] : 0.f;
+      const float* tabr = p.tab ? p.tab + (size_t)(m % p.tab_mod + p.tab_off) * p.N : nullptr;
+      size_t obase;
+      if constexpr (STORE == VDN_ST_CONVT) {
+        const int hw = p.cH * p.cW;
+        const int cb = m / hw, rem = m - cb * hw;
+        const int cy = rem / p.cW, cx = rem - cy * p.cW;
+        obase = ((size_t)cb * (p.cH * p.ck) + cy * p.ck) * (p.cW * p.ck) + cx * p.ck;  // pixel index of tap (0,0)
+      } else {
+        obase = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        f32x4 a = acc[i][j];
+        if (p.bias) a += *(const f32x4*)(p.bias + n);
+        a += radd;
+        if (p.act == VDN_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = gelu_fast(a[e]);
+        } else if (p.act == VDN_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+        }
+        if (p.gamma) a *= *(const f32x4*)(p.gamma + n);
+        if (tabr) a += *(const f32x4*)(tabr + n);
+        if (p.res1) {
+          a += load4_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n);
+          if (p.res1_lo) a += load4_as_float(p.res1_lo, p.res1_dt, (size_t)m * p.ldr1 + n);
+        }
+        if (p.res2) {
+          a += load4_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n);
+          if (p.res2_lo) a += load4_as_float(p.res2_lo, p.res2_dt, (size_t)m * p.ldr2 + n);
+        }
+        size_t o;
+        if constexpr (STORE == VDN_ST_CONVT) {
+          const int kk = n / p.cout, co = n - kk * p.cout;  // cout % 4 == 0: the 4 columns share a tap
+          const int ky = kk / p.ck, kx = kk - ky * p.ck;
+          o = (obase + (size_t)ky * (p.cW * p.ck) + kx) * p.cout + co;
+        } else {
+          o = obase + n;
+        }
+        if (p.out_dt == VDN_F32) {
+          *(f32x4*)((float*)p.out + o) = a;
+        } else if (p.out_lo) {
+          typename H::V4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+          *(typename H::V4*)((T*)p.out + o) = h;
+          *(typename H::V4*)((T*)p.out_lo + o) = l;
+        } else {
+          typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
+          *(typename H::V4*)((T*)p.out + o) = h;
+        }
+      }
+    } else if constexpr (STORE == VDN_ST_GEGLU) {
+      // packed columns: 16-wide blocks alternate [h | gate]; the pair sits in tiles (j, j+1) of this lane
+#pragma unroll
+      for (int j = 0; j + 1 < TN; j += 2) {
+        const int nh = nw + j * 16 + fq * 4;
+        if (nh + 16 >= p.N) continue;
+        f32x4 hv = acc[i][j], gv = acc[i][j + 1];
+        if (p.bias) { hv += *(const f32x4*)(p.bias + nh); gv += *(const f32x4*)(p.bias + nh + 16); }
+        f32x4 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = hv[e] * gelu_fast(gv[e]);
+        const size_t o = (size_t)m * p.ldc + ((nw + j * 16) >> 1) + fq * 4;
+        if (p.out_dt == VDN_F32) {
+          *(f32x4*)((float*)p.out + o) = a;
+        } else if (p.out_lo) {
+          typename H::V4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+          *(typename H::V4*)((T*)p.out + o) = h;
+          *(typename H::V4*)((T*)p.out_lo + o) = l;
+        } else {
+          typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
+          *(typename H::V4*)((T*)p.out + o) = h;
+        }
+      }
+    } else {  // VDN_ST_HEADS
+      const int hc = p.heads * 64;
+      const int bt = m / p.tokens, tl = m - bt * p.tokens;
+      const int tk = tl + p.tok_off;
+      const float* cs = p.rope_cs ? p.rope_cs + (size_t)(tl % p.rope_mod) * 64 : nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        const int split = n / hc;
+        const int head = (n - split * hc) >> 6, e0 = n & 63;
+        const size_t hb = (size_t)bt * p.heads + head;
+        T* dst = (T*)p.dst[split];
+        T* dlo = (T*)p.dst_lo[split];
+        f32x4 a = acc[i][j];
+        if (p.bias) a += *(const f32x4*)(p.bias + n);
+        if (p.rope[split]) {
+          if (e0 & 16) continue;  // imaginary tile: consumed together with its real partner (tile j-1)
+          if constexpr (TN > 1) {
+            if (j + 1 < TN) {
+              f32x4 b = acc[i][j + 1 < TN ? j + 1 : j];
+              if (p.bias) b += *(const f32x4*)(p.bias + n + 16);
+              const int pi = ((e0 >> 5) << 4) + (e0 & 15);  // first of 4 consecutive pair indices
+              float o8[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float cc = cs[2 * (pi + e)], ss = cs[2 * (pi + e) + 1];
+                o8[2 * e] = a[e] * cc - b[e] * ss;
+                o8[2 * e + 1] = a[e] * ss + b[e] * cc;
+              }
+              if (p.transposed[split]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) store_half(dst, dlo, (hb * 64 + 2 * pi + e) * p.tpad + tk, o8[e]);
+              } else {
+                const size_t o = (hb * p.tpad + tk) * 64 + 2 * pi;
+                typename H::V8 h8, l8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  if (dlo) { T x0, x1; split_rtz(o8[e], x0, x1); h8[e] = x0; l8[e] = x1; }
+                  else h8[e] = (T)o8[e];
+                }
+                *(typename H::V8*)(dst + o) = h8;
+                if (dlo) *(typename H::V8*)(dlo + o) = l8;
+              }
+            }
+          }
+          continue;
+        }
+        if (p.transposed[split]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) store_half(dst, dlo, (hb * 64 + e0 + e) * p.tpad + tk, a[e]);
+        } else {
+          const size_t o = (hb * p.tpad + tk) * 64 + e0;
+          typename H::V4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (dlo) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+            else h[e] = (T)a[e];
+          }
+          *(typename H::V4*)(dst + o) = h;
+          if (dlo) *(typename H::V4*)(dlo + o) = l;
+        }
+      }
+    }
+  }
+}
+
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void epilogue_dispatch(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
+  switch (p.store) {
+    case VDN_ST_PLAIN: epilogue_regs<DT, TM, TN, VDN_ST_PLAIN>(acc, p, mw, nw, lane); break;
+    case VDN_ST_CONVT: epilogue_regs<DT, TM, TN, VDN_ST_CONVT>(acc, p, mw, nw, lane); break;
+    case VDN_ST_GEGLU: epilogue_regs<DT, TM, TN, VDN_ST_GEGLU>(acc, p, mw, nw, lane); break;
+    default: epilogue_regs<DT, TM, TN, VDN_ST_HEADS>(acc, p, mw, nw, lane); break;
+  }
+}
+
+template <int DT, int BM, int BN, int WM, int WN, int AMODE /*0 plain,1 conv,2 conv+relu,3 plain+relu*/>
+__global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 1-KiB DMA pieces per wave and operand
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  // ---- staging geometry (fixed per lane over the whole K loop)
+  const int lr = lane >> 3;                                   // row inside an 8-row DMA piece
+  const int chunk = (lane & 7) ^ ((((wave & 1) << 2) + (lr >> 1)) & 7);  // source 16-B chunk
+  const T* a_row[A_IT];
+  int a_iy[A_IT], a_ix[A_IT];
+  const T* A = (const T*)p.A;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + (i * 4 + wave) * 8 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const T* b_row[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    int n = n0 + (i * 4 + wave) * 8 + lr;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
+  }
+  const T* zeros = (const T*)p.zeros;
+  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+
+  // K segments: [A_hi x W_hi] (+ [A_hi x W_lo]) (+ [A_lo x W_hi]) — the split-precision planes are
+  // just further stretches of the same accumulation loop, selected by a plane byte offset.
+  const int nk1 = p.ldb / BK;
+  const int seg_wlo = p.W_lo ? 1 : -1;
+  const int nseg = 1 + (p.W_lo ? 1 : 0) + (p.A_lo ? 1 : 0);
+  const int seg_alo = p.A_lo ? nseg - 1 : -1;
+  const ptrdiff_t a_delta = p.A_lo ? (const char*)p.A_lo - (const char*)p.A : 0;
+  const ptrdiff_t w_delta = p.W_lo ? (const char*)p.W_lo - (const char*)p.W : 0;
+
+  auto stage = [&](int buf, int kt_all) {
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
+    const int seg = kt_all / nk1;
+    const int kt = kt_all - seg * nk1;
+    const ptrdiff_t ad = (seg == seg_alo) ? a_delta : 0;
+    const ptrdiff_t wd = (seg == seg_wlo) ? w_delta : 0;
+    const int k = kt * BK + chunk * 8;
+    if constexpr (CONV) {
+      // (tap, ci) of this lane's chunk; Cin % 8 == 0 so a chunk never straddles two taps
+      const int kc = k >> 3;
+      const int tap = (int)(((float)kc + 0.5f) * inv_cin);
+      const int ci = k - tap * p.cC;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+        const char* src = ok ? (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci) + ad : (const char*)zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
+                                         16, 0, 0);
+      }
+    } else {
+      const bool ok = k < p.K;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const char* src = ok ? (const char*)(a_row[i] + k) + ad : (const char*)zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
+                                         16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const char* src = (const char*)(b_row[i] + k) + wd;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sB + (i * 4 + wave) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  // ---- fragment read geometry
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_off[t][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_off[t][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = nk1 * nseg;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sA = smem + cur * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      V8 af[TM], bf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        af[t] = *(const V8*)(sA + a_off[t][kk]);
+        if constexpr (RELU_A) af[t] = relu8(af[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[t] = *(const V8*)(sB + b_off[t][kk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = H::mfma16(bf[j], af[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  epilogue_dispatch<DT, TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+// Split-precision main loop with the planes FUSED per K step (BK = 32): one stage holds
+// A_hi, A_lo, W_hi, W_lo tiles; every fragment is read from LDS once and feeds
+// hi*hi + hi*lo + lo*hi, i.e. 16 ds_read_b128 per 48 MFMAs (vs 16 per 32 in the 1-product loop) and
+// 1.5x more MFMA work per barrier. 64-byte LDS rows, swizzle chunk ^ ((-(row>>2)) & 3) keeps the
+// ds_read_b128 lane groups {0-3,12-15,20-27}.. on 16 distinct 16-byte slots.
+template <int DT, int AMODE /*0 plain,1 conv,2 conv+relu,3 plain+relu*/>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, BK3 = 32;
+  constexpr int TILE = 128 * BK3 * 2;           // 8 KiB per operand plane
+  constexpr int STAGE = 4 * TILE;               // A_hi | A_lo | W_hi | W_lo
+  constexpr int WTM = 64, WTN = 64, TM = 4, TN = 4;
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  // staging: a 1-KiB DMA piece = 16 rows x 64 B; each wave moves pieces 2w, 2w+1 of every plane
+  const int lr = lane >> 2;                                   // row inside the piece
+  const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);     // source 16-B chunk (row>>2 == lane>>4 mod 4)
+  const T* a_row[2];
+  int a_iy[2], a_ix[2];
+  const T* A = (const T*)p.A;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + (wave * 2 + i) * 16 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const T* b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int n = n0 + (wave * 2 + i) * 16 + lr;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
+  }
+  const char* zeros = (const char*)p.zeros;
+  const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
+  const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
+  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+
+#define VDN_GLDS(src, dst)                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+  auto stage = [&](int buf, int kt) {
+    char* s0 = smem + buf * STAGE;
+    const int k = kt * BK3 + chunk * 8;
+    int ky = 0, kx = 0, ci = 0;
+    bool kok = k < p.K;
+    if constexpr (CONV) {
+      const int tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
+      ci = k - tap * p.cC;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+      kok = tap < 9;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave * 2 + i;
+      const char* src;
+      bool ok = kok;
+      if constexpr (CONV) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+        src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+      } else {
+        src = (const char*)(a_row[i] + k);
+      }
+      VDN_GLDS(ok ? src : zeros, s0 + pc * 1024);
+      VDN_GLDS(ok ? src + a_delta : zeros, s0 + TILE + pc * 1024);
+      const char* ws = (const char*)(b_row[i] + k);
+      VDN_GLDS(ws, s0 + 2 * TILE + pc * 1024);
+      VDN_GLDS(ws + w_delta, s0 + 3 * TILE + pc * 1024);
+    }
+  };
+#undef VDN_GLDS
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TM], b_off[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 16 + fr;
+    a_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * 16 + fr;
+    b_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.ldb / BK3;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* s0 = smem + cur * STAGE;
+    V8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      ah[t] = *(const V8*)(s0 + a_off[t]);
+      al[t] = *(const V8*)(s0 + TILE + a_off[t]);
+      if constexpr (RELU_A) { ah[t] = relu8(ah[t]); al[t] = relu8(al[t]); }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      bh[t] = *(const V8*)(s0 + 2 * TILE + b_off[t]);
+      bl[t] = *(const V8*)(s0 + 3 * TILE + b_off[t]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = H::mfma16(bh[j], al[i], acc[i][j]);
+        acc[i][j] = H::mfma16(bl[j], ah[i], acc[i][j]);
+        acc[i][j] = H::mfma16(bh[j], ah[i], acc[i][j]);
+      }
+    __syncthreads();
+  }
+  epilogue_dispatch<DT, TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+// Large-tile split-precision main loop: BM x 256 x 32, 8 waves (2 x 4, wave tile BM/2 x 64), one
+// workgroup per CU. Per K step a CU moves (BM + 256) * 128 B into LDS for BM*256*32*3 MACs:
+// 150-200 flop per byte, which is what the ~25 B/clk/CU global->LDS path can feed (the 128 x 128
+// tile needs 43 B/clk at full MFMA rate and stalls on it — profiles/r01_*).
+// BM in {128, 192, 256} is chosen per launch so that the tile count fills the 256 CUs evenly.
+template <int DT, int AMODE, int BM, int STORE>
+__global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  constexpr int BN = 256, BK3 = 32;
+  constexpr int A_TILE = BM * 64, W_TILE = BN * 64;      // bytes per plane
+  constexpr int STAGE = 2 * A_TILE + 2 * W_TILE;         // A_hi | A_lo | W_hi | W_lo
+  constexpr int TMW = BM / 32, TNW = 4, HALF = TMW / 2;  // frags per wave, A processed in two halves
+  constexpr int AP = BM / 16, WP = BN / 16;              // 1-KiB pieces per plane
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  // tile order inside an XCD's run: groups of 4 m-tiles walk n first, so that the ~32 tiles an
+  // XCD has in flight share A rows 8-fold and W columns 4-fold through its L2
+  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm_i, tn_i;
+  {
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int g = tile / per_group, r = tile - g * per_group;
+    const int gm = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tn_i = r / gm;
+    tm_i = g * GM + (r - tn_i * gm);
+  }
+  const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+  const int lr = lane >> 2;
+  const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+  const T* A = (const T*)p.A;
+  const T* a_row[2];
+  int a_iy[2], a_ix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pc = wave + 8 * i;
+    int m = m0 + pc * 16 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const T* b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int n = n0 + (wave + 8 * i) * 16 + lr;
+    n = n < p.N ? n : p.N - 1;
+    b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
+  }
+  const char* zeros = (const char*)p.zeros;
+  const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
+  const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
+  const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+
+#define VDN_GLDS(src, dst)                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+  auto stage = [&](int buf, int kt) {
+    char* s0 = smem + buf * STAGE;
+    const int k = kt * BK3 + chunk * 8;
+    int ky = 0, kx = 0, ci = 0;
+    bool kok = k < p.K;
+    if constexpr (CONV) {
+      const int tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
+      ci = k - tap * p.cC;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+      kok = tap < 9;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < AP) {
+        const char* src;
+        bool ok = kok;
+        if constexpr (CONV) {
+          const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+          ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+          src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+        } else {
+          src = (const char*)(a_row[i] + k);
+        }
+        VDN_GLDS(ok ? src : zeros, s0 + pc * 1024);
+        VDN_GLDS(ok ? src + a_delta : zeros, s0 + A_TILE + pc * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i;
+      const char* ws = (const char*)(b_row[i] + k);
+      VDN_GLDS(ws, s0 + 2 * A_TILE + pc * 1024);
+      VDN_GLDS(ws + w_delta, s0 + 2 * A_TILE + W_TILE + pc * 1024);
+    }
+  };
+  // plain rows: per-lane source pointers advance by 64 B per K step (no per-step address math)
+  const char* ap[2][2];
+  const char* wp[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ap[i][0] = (const char*)(a_row[i] + chunk * 8);
+    ap[i][1] = ap[i][0] + a_delta;
+    wp[i][0] = (const char*)(b_row[i] + chunk * 8);
+    wp[i][1] = wp[i][0] + w_delta;
+  }
+  auto stage_plain = [&](int buf) {
+    char* s0 = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < AP) {
+        VDN_GLDS(ap[i][0], s0 + pc * 1024);
+        VDN_GLDS(ap[i][1], s0 + A_TILE + pc * 1024);
+        ap[i][0] += 64;
+        ap[i][1] += 64;
+      }
+      VDN_GLDS(wp[i][0], s0 + 2 * A_TILE + pc * 1024);
+      VDN_GLDS(wp[i][1], s0 + 2 * A_TILE + W_TILE + pc * 1024);
+      wp[i][0] += 64;
+      wp[i][1] += 64;
+    }
+  };
+#undef VDN_GLDS
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TMW], b_off[TNW];
+#pragma unroll
+  for (int t = 0; t < TMW; ++t) {
+    const int row = wm * (BM / 2) + t * 16 + fr;
+    a_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TNW; ++t) {
+    const int row = wn * 64 + t * 16 + fr;
+    b_off[t] = 2 * A_TILE + row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[TMW][TNW];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.ldb / BK3;
+  if constexpr (CONV) stage(0, 0); else stage_plain(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      if constexpr (CONV) stage(cur ^ 1, kt + 1); else stage_plain(cur ^ 1);
+    }
+    const char* s0 = smem + cur * STAGE;
+    V8 bh[TNW], bl[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+      bh[t] = *(const V8*)(s0 + b_off[t]);
+      bl[t] = *(const V8*)(s0 + W_TILE + b_off[t]);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      V8 ah[HALF], al[HALF];
+#pragma unroll
+      for (int t = 0; t < HALF; ++t) {
+        ah[t] = *(const V8*)(s0 + a_off[hf * HALF + t]);
+        al[t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
+        if constexpr (RELU_A) { ah[t] = relu8(ah[t]); al[t] = relu8(al[t]); }
+      }
+#pragma unroll
+      for (int i = 0; i < HALF; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          f32x4 c = acc[hf * HALF + i][j];
+          c = H::mfma16(bh[j], al[i], c);
+          c = H::mfma16(bl[j], ah[i], c);
+          c = H::mfma16(bh[j], ah[i], c);
+          acc[hf * HALF + i][j] = c;
+        }
+    }
+    __syncthreads();
+  }
+
+  epilogue_regs<DT, TMW, TNW, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+}
+
+template <int DT, int BM, int BN, int WM, int WN>
+int launch_tile(const vdn_gemm_desc& d, hipStream_t s) {
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+  const bool conv = d.a_mode == VDN_A_CONV3X3;
+  const int amode = conv ? (d.relu_a ? 2 : 1) : (d.relu_a ? 3 : 0);
+  switch (amode) {
+    case 0: hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), lds, s, d); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), lds, s, d); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, 2>), dim3(tiles), dim3(256), lds, s, d); break;
+    default: hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, 3>), dim3(tiles), dim3(256), lds, s, d); break;
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+template <int DT>
+int launch_x3(const vdn_gemm_desc& d, hipStream_t s) {
+  const int tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128);
+  const size_t lds = 65536;  // 2 stages x 4 planes x 8 KiB
+  const bool conv = d.a_mode == VDN_A_CONV3X3;
+  const int amode = conv ? (d.relu_a ? 2 : 1) : (d.relu_a ? 3 : 0);
+  switch (amode) {
+    case 0: hipLaunchKernelGGL((gemm_x3_kernel<DT, 0>), dim3(tiles), dim3(256), lds, s, d); break;
+    case 1: hipLaunchKernelGGL((gemm_x3_kernel<DT, 1>), dim3(tiles), dim3(256), lds, s, d); break;
+    case 2: hipLaunchKernelGGL((gemm_x3_kernel<DT, 2>), dim3(tiles), dim3(256), lds, s, d); break;
+    default: hipLaunchKernelGGL((gemm_x3_kernel<DT, 3>), dim3(tiles), dim3(256), lds, s, d); break;
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+template <int DT, int BM>
+int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + 255) / 256);
+  const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * 256 * 64);
+  const dim3 g(tiles), b(512);
+  if (d.a_mode == VDN_A_CONV3X3) {  // convolutions always store plain NHWC rows
+    if (d.relu_a) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, BM, VDN_ST_PLAIN>), g, b, lds, s, d);
+    else hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 1, BM, VDN_ST_PLAIN>), g, b, lds, s, d);
+  } else {
+    switch (d.store) {
+      case VDN_ST_PLAIN: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_PLAIN>), g, b, lds, s, d); break;
+      case VDN_ST_CONVT: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_CONVT>), g, b, lds, s, d); break;
+      case VDN_ST_GEGLU: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_GEGLU>), g, b, lds, s, d); break;
+      default: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_HEADS>), g, b, lds, s, d); break;
+    }
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+template <int DT> int big_entry(const vdn_gemm_desc& d, int bm, hipStream_t s);  // defined in gemm_big_*.hip
+
+// Pick the M tile that wastes the fewest CU-rounds: cost = rounds(256 CUs) * BM, padded work included.
+inline int pick_bm(int M, int N) {
+  const int tn = (N + 255) / 256;
+  int best = 0;
+  double best_cost = 1e30;
+  for (int bm : {256, 192, 128}) {
+    const long tiles = (long)((M + bm - 1) / bm) * tn;
+    const long rounds = (tiles + 255) / 256;
+    const double cost = (double)rounds * bm * (bm == 128 ? 1.12 : (bm == 192 ? 1.04 : 1.0));  // smaller tiles feed worse
+    if (cost < best_cost) { best_cost = cost; best = bm; }
+  }
+  return best;
+}
+
+template <int DT>
+int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
+  if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024 &&
+      (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
+    const char* force = getenv("VDN_GEMM_BM");
+    const int bm = force ? atoi(force) : pick_bm(d.M, d.N);
+    if (bm == 256 || bm == 192 || bm == 128) return big_entry<DT>(d, bm, s);
+  }
+  if (d.A_lo && d.W_lo && (d.store == VDN_ST_HEADS || d.N > 64)) return launch_x3<DT>(d, s);
+  if (d.store == VDN_ST_HEADS || d.N > 64) return launch_tile<DT, 128, 128, 2, 2>(d, s);
+  if (d.N > 32) return launch_tile<DT, 128, 64, 2, 2>(d, s);
+  return launch_tile<DT, 128, 32, 4, 1>(d, s);
+}
+
+
+}  // namespace vdn_gemm_impl

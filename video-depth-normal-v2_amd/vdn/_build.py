@@ -10,7 +10,8 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libvdn_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "spatial.hip"]
+SOURCES = ["gemm_big_f16.hip", "gemm_big_bf16.hip", "gemm_small_f16.hip", "gemm_small_bf16.hip", "gemm.hip", "attn.hip",
+           "norm.hip", "spatial.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -24,7 +25,7 @@ def _newer(src_list, target):
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(os.path.dirname(PKG), "include", "vdn.h")]
+    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_kernels.hpp"), os.path.join(os.path.dirname(PKG), "include", "vdn.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -39,7 +40,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         subprocess.run(cmd, check=True)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=4) as ex:
+        with ThreadPoolExecutor(max_workers=6) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _newer(objs, LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
