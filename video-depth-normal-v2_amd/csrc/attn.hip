@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
           o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
         }
       }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
 

@@ -16,6 +16,7 @@
 #pragma once
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace vdn_gemm_impl {
 
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = H::mfma16(bf[j], af[i], acc[i][j]);
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
 
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
         acc[i][j] = H::mfma16(bl[j], ah[i], acc[i][j]);
         acc[i][j] = H::mfma16(bh[j], ah[i], acc[i][j]);
       }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
   epilogue_dispatch<DT, TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 8 * i;
-      if (pc < AP) {
+      if (AP == 16 || pc < AP) {
         VDN_GLDS(ap[i][0], s0 + pc * 1024);
         VDN_GLDS(ap[i][1], s0 + A_TILE + pc * 1024);
         ap[i][0] += 64;
@@ -660,9 +663,12 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   const int nk = p.ldb / BK3;
   if constexpr (CONV) stage(0, 0); else stage_plain(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+
+  // one K step on stage `cur`; STAGED: the next stage's DMA is issued inside the step
+  auto step = [&](int kt, auto staged) {
+    constexpr bool STAGED = decltype(staged)::value;
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
+    if constexpr (STAGED) {
       if constexpr (CONV) stage(cur ^ 1, kt + 1); else stage_plain(cur ^ 1);
     }
     const char* s0 = smem + cur * STAGE;
@@ -672,28 +678,47 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
       bh[t] = *(const V8*)(s0 + b_off[t]);
       bl[t] = *(const V8*)(s0 + W_TILE + b_off[t]);
     }
+    V8 ah[2][HALF], al[2][HALF];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      V8 ah[HALF], al[HALF];
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int t = 0; t < HALF; ++t) {
-        ah[t] = *(const V8*)(s0 + a_off[hf * HALF + t]);
-        al[t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
-        if constexpr (RELU_A) { ah[t] = relu8(ah[t]); al[t] = relu8(al[t]); }
+        ah[hf][t] = *(const V8*)(s0 + a_off[hf * HALF + t]);
+        al[hf][t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
+        if constexpr (RELU_A) { ah[hf][t] = relu8(ah[hf][t]); al[hf][t] = relu8(al[hf][t]); }
       }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int i = 0; i < HALF; ++i)
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
           f32x4 c = acc[hf * HALF + i][j];
-          c = H::mfma16(bh[j], al[i], c);
-          c = H::mfma16(bl[j], ah[i], c);
-          c = H::mfma16(bh[j], ah[i], c);
+          c = H::mfma16(bh[j], al[hf][i], c);
+          c = H::mfma16(bl[j], ah[hf][i], c);
+          c = H::mfma16(bh[j], ah[hf][i], c);
           acc[hf * HALF + i][j] = c;
         }
+    // Issue order for the scheduler: W + first-half A fragments, then the first half's MFMAs with the
+    // next stage's LDS-DMA pieces and the second half's A fragment reads threaded through them (the
+    // DMA issue would otherwise idle the matrix pipe of BOTH waves of a SIMD right after the barrier).
+    if constexpr (!CONV && STAGED && AP == 16) {
+      constexpr int NM = HALF * TNW * 3;  // MFMAs per half
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TNW + 2 * HALF, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (g < 2 * HALF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
+  step(nk - 1, std::false_type{});
 
   epilogue_regs<DT, TMW, TNW, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
