@@ -30,6 +30,17 @@ import torch  # noqa: E402
 PEAK_TFLOPS_F16 = 2500.0  # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _pmc_traffic(prec_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(prec_name, {}).get("enc_linear_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +153,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "kernel": "gemm_kernel<128x128x64> on the 4 encoder linears (qkv, proj, fc1, fc2)",
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
-                "traffic": None, "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
+                "traffic": _pmc_traffic(prec_name), "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_gflop_per_launch": round(flop_per_launch / 1e9, 2),
                 "mfma_products_per_term": nprod, "executed_frac": round(nprod * ach / PEAK_TFLOPS_F16, 4)}
         att = [s.elapsed_time(e) for (tag, s, e) in ev if tag == "enc_attn"]
@@ -169,7 +180,9 @@ def main():
         from oracle import ref_cpu as O
         sd_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
         xc = x.reshape(-1, 3, H, W)[:1].cpu()
-        threads = torch.get_num_threads()
+        # the GPU box gives one GPU a 16-core CPU share: oversubscribing all visible cores is slower
+        threads = min(torch.get_num_threads(), int(os.environ.get("VDN_CPU_THREADS", "16")))
+        torch.set_num_threads(threads)
         with torch.no_grad():
             t0 = time.perf_counter()
             if a.workload == "stream":

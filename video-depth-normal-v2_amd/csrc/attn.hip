@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
           o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
         }
       }
+#ifdef VDN_ATTN_PIN
     __builtin_amdgcn_sched_barrier(0);
+#endif
     __syncthreads();
   }
 

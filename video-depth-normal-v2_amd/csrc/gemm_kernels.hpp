@@ -345,7 +345,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = H::mfma16(bf[j], af[i], acc[i][j]);
     }
-    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
 
@@ -494,7 +493,6 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
         acc[i][j] = H::mfma16(bl[j], ah[i], acc[i][j]);
         acc[i][j] = H::mfma16(bh[j], ah[i], acc[i][j]);
       }
-    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
   epilogue_dispatch<DT, TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
@@ -699,22 +697,6 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
           c = H::mfma16(bh[j], ah[hf][i], c);
           acc[hf * HALF + i][j] = c;
         }
-    // Issue order for the scheduler: W + first-half A fragments, then the first half's MFMAs with the
-    // next stage's LDS-DMA pieces and the second half's A fragment reads threaded through them (the
-    // DMA issue would otherwise idle the matrix pipe of BOTH waves of a SIMD right after the barrier).
-    if constexpr (!CONV && STAGED && AP == 16) {
-      constexpr int NM = HALF * TNW * 3;  // MFMAs per half
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TNW + 2 * HALF, 0);
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if (g < 2 * HALF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   };
   for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});

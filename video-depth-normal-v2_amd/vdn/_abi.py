@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG, "lib", "libvdn_hip.so")
+LIB_PATH = os.environ.get("VDN_LIB") or os.path.join(PKG, "lib", "libvdn_hip.so")
 
 F16, BF16, F32, NONE = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
