@@ -162,3 +162,23 @@ def test_single_pass_modes_error_is_reported_and_bounded(precision, limit):
         e = rel_l2(torch.relu(pre[:, ::sub, ::sub]), np.maximum(g[f"pre_{t}"], 0))
         print(f"[A_vitl_518 {precision}] frame {t}: vs reference fixture post-ReLU {e:.2e}")
         assert e < limit
+
+
+def test_frame_sharded_forward_matches_plain_on_one_rank():
+    """vdn/dist.py path with a world of 1 (the exchange is the identity): same kernels, same result as
+    forward(); the 2-rank exchange itself is covered on CPU/gloo in tests/test_dist.py."""
+    model = _product("B", "vits")
+    x = inputs(4, 266, 266).reshape(1, 4, 3, 266, 266)
+    a = model.forward(x.cuda()).cpu()
+    b = model.forward_sharded(x.cuda()).cpu()
+    assert rel_l2(b, a) < 1e-6
+
+
+def test_window_sharded_driver_single_rank():
+    from vdn import synth
+    from vdn.dist import infer_video_depth_sharded
+    model = _product("B", "vits")
+    frames = synth.frames_u8(1234, 40, 140, 140)
+    d0, _ = model.infer_video_depth(frames, 24, input_size=140)
+    d1, _ = infer_video_depth_sharded(model, frames, 24, input_size=140)
+    assert np.allclose(d0, d1, rtol=1e-5, atol=1e-6)

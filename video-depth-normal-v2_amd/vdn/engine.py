@@ -134,31 +134,65 @@ class TemporalEngine:
         self.wf2, self.bf2 = pack.linear(blk.ff.net[2].weight, h), pack.f32(blk.ff.net[2].bias)
         self.w_out, self.b_out = pack.linear(tt.proj_out.weight, h), pack.f32(tt.proj_out.bias)
 
-    def run(self, x: torch.Tensor, B: int, T: int, HW: int) -> torch.Tensor:
-        """x half [(b f) * HW, c] (NHWC frames) -> same shape."""
+    def gn(self, x, F: int, HW: int):
+        """GroupNorm(32, eps 1e-6) per frame (motion_module.py:112): needs all pixels of a frame."""
+        g = self.rt.hbuf("tm_gn", (F * HW, self.c))
+        self.rt.groupnorm(x, g, F, HW, self.c, 32, self.gnw, self.gnb, 1e-6)
+        return g
+
+    def core(self, g, B: int, T: int, D: int):
+        """proj_in -> 2 x (LN + PE, q/k/v, attention over frames, out) -> GEGLU FF (motion_module.py:116-192).
+        Everything here is per pixel, so `D` may be any subset of a frame's pixels (vdn/dist.py)."""
         rt, c = self.rt, self.c
-        M = B * T * HW
+        M = B * T * D
         assert T <= self.att[0]["pe"].shape[0], "clip longer than temporal_max_len (motion_module.py:200-213)"
-        g = rt.hbuf("tm_gn", (M, c))
-        rt.groupnorm(x, g, B * T, HW, c, 32, self.gnw, self.gnb, 1e-6)
         hs = rt.fbuf("tm_h", (M, c))
         rt.gemm(g, self.w_in, M, c, c, bias=self.b_in, out=hs)
         n = rt.hbuf("tm_n", (M, c))
         qkv = rt.hbuf("tm_qkv", (M, 3 * c))
         a = rt.hbuf("tm_a", (M, c))
         for at in self.att:
-            rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n, addtab=at["pe"], tab_div=HW, tab_mod=T)
+            rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n, addtab=at["pe"], tab_div=D, tab_mod=T)
             rt.gemm(n, at["wqkv"], M, 3 * c, c, out=qkv)
-            rt.temporal_attn(qkv, a, B, T, HW, c, 8, (c // 8) ** -0.5)
+            rt.temporal_attn(qkv, a, B, T, D, c, 8, (c // 8) ** -0.5)
             rt.gemm(a, at["wo"], M, c, c, bias=at["bo"], res1=hs, out=hs)
         rt.layernorm(hs, M, c, self.fnw, self.fnb, 1e-5, out_h=n)
         gg = rt.hbuf("tm_gg", (M, 4 * c))
         rt.gemm(n, self.wg, M, 8 * c, c, bias=self.bg, store=abi.ST_GEGLU, out=gg)
         hh = rt.hbuf("tm_hh", (M, c))
         rt.gemm(gg, self.wf2, M, c, 4 * c, bias=self.bf2, res1=hs, out=hh)
-        y = rt.hbuf(f"tm_out{self.idx}", (M, c))
-        rt.gemm(hh, self.w_out, M, c, c, bias=self.b_out, res1=x, out=y)
+        return hh
+
+    def out(self, hh, x, M: int):
+        """proj_out + residual with the module input (motion_module.py:131-135)."""
+        y = self.rt.hbuf(f"tm_out{self.idx}", (M, self.c))
+        self.rt.gemm(hh, self.w_out, M, self.c, self.c, bias=self.b_out, res1=x, out=y)
         return y
+
+    def run(self, x, B: int, T: int, HW: int):
+        """x half [(b f) * HW, c] (NHWC frames) -> same shape."""
+        return self.out(self.core(self.gn(x, B * T, HW), B, T, HW), x, B * T * HW)
+
+    def run_sharded(self, x, exch, HW: int):
+        """Frame-sharded window (vdn/dist.py): x holds this rank's Tl frames. GroupNorm and proj_out run
+        on the frame shard; the per-pixel core runs on all T frames of this rank's pixel shard, with one
+        all-to-all before and one after (hi and lo planes travel together)."""
+        from .runtime import HL
+        c, Tl = self.c, exch.Tl
+        g = self.gn(x, Tl, HW)
+
+        def planes(t):
+            return torch.cat([t.hi.reshape(Tl, HW, c)] + ([t.lo.reshape(Tl, HW, c)] if t.lo is not None else []), dim=-1)
+
+        gp = exch.frames_to_pixels(planes(g))                     # [T, HWp, c * planes]
+        D = gp.shape[1]
+        gsh = HL(gp[..., :c].contiguous().reshape(-1, c), gp[..., c:].contiguous().reshape(-1, c) if g.lo is not None else None)
+        hh = self.core(gsh, 1, exch.T, D)
+        hp = torch.cat([hh.hi.reshape(exch.T, D, c)] + ([hh.lo.reshape(exch.T, D, c)] if hh.lo is not None else []), dim=-1)
+        hl = exch.pixels_to_frames(hp, HW)                        # [Tl, HW, c * planes]
+        hloc = HL(hl[..., :c].contiguous().reshape(-1, c), hl[..., c:].contiguous().reshape(-1, c) if hh.lo is not None else None)
+        self.rt._keep.append((gsh, hloc))
+        return self.out(hloc, x, Tl * HW)
 
 
 # =============================================================================================
@@ -226,7 +260,8 @@ class DPTEngine:
         rt.upsample(v, p, Bf, H, W, OH, OW, F)
         return p
 
-    def run(self, taps: List[torch.Tensor], Bf: int, ph: int, pw: int, T: Optional[int] = None, relu: bool = True):
+    def run(self, taps: List[torch.Tensor], Bf: int, ph: int, pw: int, T: Optional[int] = None, relu: bool = True,
+            exch=None):
         rt, C, F, oc = self.rt, self.C, self.F, self.oc
         P = ph * pw
         pr = []
@@ -244,20 +279,24 @@ class DPTEngine:
                 convt=dict(k=2, cout=oc[1], B=Bf, H=ph, W=pw))
         l3 = pr[2]
         l4 = self._conv3(pr[3], self.rs3[0], Bf, ph, pw, oc[3], oc[3], "l4", stride=2, bias=self.rs3[1])
+        def tm(i, x, hw):
+            if exch is not None:  # frame-sharded window: Bf == this rank's frames of ONE clip
+                return self.temporal[i].run_sharded(x, exch, hw)
+            return self.temporal[i].run(x, Bf // T, T, hw)
+
         if self.temporal is not None:
-            B = Bf // T
-            l3 = self.temporal[0].run(l3, B, T, s3[0] * s3[1])
-            l4 = self.temporal[1].run(l4, B, T, s4[0] * s4[1])
+            l3 = tm(0, l3, s3[0] * s3[1])
+            l4 = tm(1, l4, s4[0] * s4[1])
         r1 = self._conv3(l1, self.rn[0], Bf, s1[0], s1[1], oc[0], F, "l1_rn")
         r2 = self._conv3(l2, self.rn[1], Bf, s2[0], s2[1], oc[1], F, "l2_rn")
         r3 = self._conv3(l3, self.rn[2], Bf, s3[0], s3[1], oc[2], F, "l3_rn")
         r4 = self._conv3(l4, self.rn[3], Bf, s4[0], s4[1], oc[3], F, "l4_rn")
         p4 = self._fusion(4, Bf, s4, s3, r4)
         if self.temporal is not None:
-            p4 = self.temporal[2].run(p4, Bf // T, T, s3[0] * s3[1])
+            p4 = tm(2, p4, s3[0] * s3[1])
         p3 = self._fusion(3, Bf, s3, s2, p4, r3)
         if self.temporal is not None:
-            p3 = self.temporal[3].run(p3, Bf // T, T, s2[0] * s2[1])
+            p3 = tm(3, p3, s2[0] * s2[1])
         p2 = self._fusion(2, Bf, s2, s1, p3, r2)
         s0 = (2 * s1[0], 2 * s1[1])
         p1 = self._fusion(1, Bf, s1, s0, p2, r1)

@@ -47,6 +47,38 @@ class VideoDepthAnything(_EngineOwner):
         return depth.reshape(B, T, H, W).clone()
 
     @torch.no_grad()
+    def forward_sharded(self, x_local: torch.Tensor, group=None, _pre_relu: bool = False) -> torch.Tensor:
+        """One window whose T frames are sharded over the ranks of `group` (this rank passes its
+        T/P consecutive frames, [1, T/P, 3, H, W]) -> depth of the local frames [1, T/P, H, W].
+        Per-frame work stays local; each temporal module re-shards frames<->pixels with an
+        all-to-all over RCCL (vdn/dist.py::FrameShardExchange)."""
+        from .dist import FrameShardExchange, world
+        e = self._engines()
+        rt, enc, head = e["rt"], e["enc"], e["head"]
+        B, Tl, _, H, W = x_local.shape
+        assert B == 1, "frame sharding is per clip"
+        exch = FrameShardExchange(Tl * world(group), group)
+        xf = x_local.to(device=rt.device, dtype=torch.float32).reshape(Tl, 3, H, W).contiguous()
+        taps, _, (ph, pw) = enc.run(xf)
+        depth = head.run(taps, Tl, ph, pw, T=exch.T, relu=not _pre_relu, exch=exch)
+        return depth.reshape(1, Tl, H, W).clone()
+
+    def preprocess_frames(self, frames: np.ndarray, input_size: int) -> torch.Tensor:
+        """u8 RGB [n,h,w,3] -> normalised f32 [n,3,H,W] on the device (video_depth.py:73-99)."""
+        rt = self._engines()["rt"]
+        dev = torch.from_numpy(np.ascontiguousarray(frames)).to(rt.device).float() / 255.0
+        return self.preprocess(rt, dev, input_size)
+
+    def resize_depth(self, d: torch.Tensor, fh: int, fw: int) -> torch.Tensor:
+        """[n,H,W] -> [n,fh,fw], bilinear align_corners (video_depth.py:111)."""
+        if tuple(d.shape[-2:]) == (fh, fw):
+            return d
+        rt = self._engines()["rt"]
+        o = torch.empty((d.shape[0], fh, fw), dtype=torch.float32, device=rt.device)
+        rt.upsample_f32(d.contiguous(), o, d.shape[0], d.shape[-2], d.shape[-1], fh, fw)
+        return o
+
+    @torch.no_grad()
     def infer_video_depth(self, frames: np.ndarray, target_fps, input_size: int = 518, device: str = "cuda",
                           fp32: bool = False):
         """frames u8 RGB [N,h,w,3] -> (f32 [N,h,w], target_fps) (video_depth.py:67-156). `fp32` is accepted for
@@ -59,16 +91,11 @@ class VideoDepthAnything(_EngineOwner):
             input_size = int(input_size * 1.777 / ratio)
             input_size = round(input_size / 14) * 14
         n = frames.shape[0]
-        dev_frames = torch.from_numpy(np.ascontiguousarray(frames)).to(rt.device).float() / 255.0
-        net_in = self.preprocess(rt, dev_frames, input_size)  # [n,3,H,W]
+        net_in = self.preprocess_frames(frames, input_size)  # [n,3,H,W]
         depth_list = []
         for idxs in util.window_table(n):
             cur = net_in[torch.tensor(idxs, device=rt.device)][None]
-            d = self.forward(cur)[0]  # [32,H,W]
-            if tuple(d.shape[-2:]) != (fh, fw):
-                o = torch.empty((INFER_LEN, fh, fw), dtype=torch.float32, device=rt.device)
-                rt.upsample_f32(d.contiguous(), o, INFER_LEN, d.shape[-2], d.shape[-1], fh, fw)
-                d = o
+            d = self.resize_depth(self.forward(cur)[0], fh, fw)  # [32,fh,fw]
             dn = d.cpu().numpy()
             depth_list += [dn[i] for i in range(INFER_LEN)]
         return util.stitch(depth_list, n), target_fps
