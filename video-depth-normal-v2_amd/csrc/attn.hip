@@ -50,8 +50,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // 1-D grid, XCD-aware: the q-blocks of one (batch, head) are consecutive logical ids and therefore run
+  // on ONE XCD, so its K / V^T tiles are fetched from HBM once and re-read by the other q-blocks from
+  // that XCD's L2 (rocprofv3 FETCH_SIZE showed 7.6x over-fetch with a round-robin 2-D grid).
+  const int nqb = (nq + 127) >> 7;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = logical / nqb;
+  const int q0 = (logical - bh * nqb) * 128 + wave * 32;
   const int r = lane & 31, h = lane >> 5;
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 ks + 8 h + j]
@@ -353,7 +358,7 @@ template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
                  void* outl, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
   using T = typename Half<DT>::T;
-  const dim3 grid((nq + 127) / 128, B * H);
+  const dim3 grid(((nq + 127) / 128) * B * H);
   if (Ql)
     hipLaunchKernelGGL((flash_attn_kernel<DT, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
