@@ -530,3 +530,59 @@ def test_x3_temporal_norms_upsample_headout(rt3):
     rows = rt3.hbuf("t3_rows", (4, 640))
     rt3.patchify(img.to(DEV), rows, 1, 28, 28, 640)
     close(rows.float()[:, :588], F.unfold(img, 14, stride=14).transpose(1, 2).reshape(4, 588), 1e-6)
+
+
+@pytest.mark.parametrize("bm", ["128", "192", "256"])
+@pytest.mark.parametrize("M,N,K", [(724, 1152, 384), (724, 384, 1536), (1370, 1152, 384), (2050, 256, 2304), (700, 1024, 64), (513, 200, 96)])
+def test_x3_big_tile_gemm_ragged(rt3, bm, M, N, K, monkeypatch):
+    """The 8-wave BM x 256 kernels on ragged M / N (tails in both), every BM variant forced."""
+    from vdn import pack, _abi
+    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    a = rnd(M, K, seed=300)
+    w = rnd(N, K, seed=301, scale=1 / math.sqrt(K))
+    b, g = rnd(N, seed=302), rnd(N, seed=303)
+    x = rnd(M, N, seed=304)
+    ref = (x.double() + (a.double() @ w.double().t() + b.double()) * g.double()).float()
+    xd = x.clone().to(DEV)
+    rt3.gemm(rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec), M, N, K, out=xd, bias=b.to(DEV), gamma=g.to(DEV), res1=xd)
+    close(xd, ref, 3e-6)
+    oh = rt3.hbuf(f"t_big_{M}_{N}", (M, N))
+    rt3.gemm(rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec), M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU)
+    close(oh.float(), F.gelu(a.double() @ w.double().t() + b.double()).float(), 3e-6)
+
+
+@pytest.mark.parametrize("bm", ["128", "256"])
+def test_x3_big_tile_heads_and_conv(rt3, bm, monkeypatch):
+    from vdn import pack, _abi
+    from vdn.runtime import ceil_to
+    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    B, T, Hh = 2, 362, 6
+    C = Hh * 64
+    a = rnd(B * T, C, seed=310)
+    w = rnd(3 * C, C, seed=311, scale=1 / math.sqrt(C))
+    b = rnd(3 * C, seed=312)
+    y = (a.double() @ w.double().t() + b.double()).float().reshape(B, T, 3, Hh, 64)
+    tp = ceil_to(T, 64)
+    q, k = rt3.hbuf("t_bq", (B * Hh, tp, 64), zero=True), rt3.hbuf("t_bk", (B * Hh, tp, 64), zero=True)
+    vt = rt3.hbuf("t_bv", (B * Hh, 64, tp), zero=True)
+    rt3.gemm(rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec), B * T, 3 * C, C, bias=b.to(DEV), store=_abi.ST_HEADS,
+             heads=dict(dst=[q, k, vt], transposed=[0, 0, 1], heads=Hh, tokens=T, tpad=tp))
+    close(q.float().reshape(B, Hh, tp, 64)[:, :, :T], y[:, :, 0].permute(0, 2, 1, 3), 3e-6)
+    close(k.float().reshape(B, Hh, tp, 64)[:, :, :T], y[:, :, 1].permute(0, 2, 1, 3), 3e-6)
+    close(vt.float().reshape(B, Hh, 64, tp)[:, :, :, :T], y[:, :, 2].permute(0, 2, 3, 1), 3e-6)
+    # conv 3x3 with relu-on-load through the big kernel (M*N >= 256K)
+    Bc, Hc, Wc, Ci, Co = 2, 40, 38, 64, 256
+    x = rnd(Bc, Hc, Wc, Ci, seed=313)
+    wc = rnd(Co, Ci, 3, 3, seed=314, scale=1 / math.sqrt(9 * Ci))
+    bc = rnd(Co, seed=315)
+    ref = F.conv2d(F.relu(x).permute(0, 3, 1, 2).double(), wc.double(), bc.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co).float()
+    xa = rt3.hbuf("t_bca", (Bc * Hc * Wc, Ci))
+    xf = x.reshape(-1, Ci).to(DEV)
+    h_rtn = xf.half()
+    hi = torch.where(h_rtn.float().abs() > xf.abs(), torch.nextafter(h_rtn, torch.zeros_like(h_rtn)), h_rtn)
+    xa.hi.copy_(hi)
+    xa.lo.copy_((xf - hi.float()).half())
+    out = rt3.hbuf("t_bco", (Bc * Hc * Wc, Co))
+    rt3.gemm(xa, pack.conv3x3(wc.to(DEV), rt3.prec), Bc * Hc * Wc, Co, 9 * Ci, out=out, bias=bc.to(DEV), relu_a=True,
+             conv=dict(B=Bc, H=Hc, W=Wc, C=Ci, OH=Hc, OW=Wc, stride=1))
+    close(out.float(), ref, 5e-6)

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
 
   const int nt = (nk + 63) >> 6;
   stage(0, 0);
-  __syncthreads();
+  stage_barrier();
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) stage(cur ^ 1, t + 1);
@@ -188,10 +188,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
           o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
         }
       }
-#ifdef VDN_ATTN_PIN
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    __syncthreads();
+    stage_barrier();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);

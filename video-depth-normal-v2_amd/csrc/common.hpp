@@ -112,6 +112,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Barrier closing a pipeline stage that (a) other waves will overwrite by LDS-DMA and (b) whose DMA for
+// the next stage this wave has issued: the wave's own LDS reads AND its LDS-DMA must have completed
+// before it arrives (hipcc alone may leave ds_reads in flight across the barrier: a WAR race against
+// the next stage's DMA, and `s_barrier` itself waits for no counter).
+__device__ __forceinline__ void stage_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // Split a float into (hi, lo) 16-bit planes: hi = x rounded TOWARD ZERO, lo = nearest(x - hi).
 // hi and lo share their sign (or lo == 0), so sign-based ops (ReLU) act per plane.
 __device__ __forceinline__ void split_rtz(float x, _Float16& hi, _Float16& lo) {

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
 
   const int nk = nk1 * nseg;
   stage(0, 0);
-  __syncthreads();
+  stage_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = H::mfma16(bf[j], af[i], acc[i][j]);
     }
-    __syncthreads();
+    stage_barrier();
   }
 
   epilogue_dispatch<DT, TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
 
   const int nk = p.ldb / BK3;
   stage(0, 0);
-  __syncthreads();
+  stage_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
         acc[i][j] = H::mfma16(bl[j], ah[i], acc[i][j]);
         acc[i][j] = H::mfma16(bh[j], ah[i], acc[i][j]);
       }
-    __syncthreads();
+    stage_barrier();
   }
   epilogue_dispatch<DT, TM, TN>(acc, p, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 
   const int nk = p.ldb / BK3;
   if constexpr (CONV) stage(0, 0); else stage_plain(0);
-  __syncthreads();
+  stage_barrier();
 
   // one K step on stage `cur`; STAGED: the next stage's DMA is issued inside the step
   auto step = [&](int kt, auto staged) {
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
           c = H::mfma16(bh[j], ah[hf][i], c);
           acc[hf * HALF + i][j] = c;
         }
-    __syncthreads();
+    stage_barrier();
   };
   for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
   step(nk - 1, std::false_type{});
