@@ -586,3 +586,22 @@ def test_x3_big_tile_heads_and_conv(rt3, bm, monkeypatch):
     rt3.gemm(xa, pack.conv3x3(wc.to(DEV), rt3.prec), Bc * Hc * Wc, Co, 9 * Ci, out=out, bias=bc.to(DEV), relu_a=True,
              conv=dict(B=Bc, H=Hc, W=Wc, C=Ci, OH=Hc, OW=Wc, stride=1))
     close(out.float(), ref, 5e-6)
+
+
+def test_x3_big_tile_k_smaller_than_padded_stride_with_poisoned_neighbour(rt3, monkeypatch):
+    """K = 96 (weights padded to 128): the A rows must not be read past K — the memory right after the
+    A buffer is NaN here, which a read of columns 96..127 of the last row would pull in (0 x NaN)."""
+    from vdn import pack, _abi
+    monkeypatch.setenv("VDN_GEMM_BM", "128")
+    M, N, K = 722, 384, 96
+    a = rnd(M, K, seed=320)
+    w = rnd(N, K, seed=321, scale=1 / math.sqrt(K))
+    slab = torch.full((2, M * K + 4096), float("nan"), device=DEV, dtype=torch.float16)
+    ah = rt3.to_half(a.to(DEV))
+    from vdn.runtime import HL
+    slab[0, : M * K] = ah.hi.reshape(-1)
+    slab[1, : M * K] = ah.lo.reshape(-1)
+    A = HL(slab[0, : M * K].reshape(M, K), slab[1, : M * K].reshape(M, K))
+    out = torch.empty(M, N, device=DEV)
+    rt3.gemm(A, pack.linear(w.to(DEV), rt3.prec), M, N, K, out=out)
+    close(out, (a.double() @ w.double().t()).float(), 3e-6)

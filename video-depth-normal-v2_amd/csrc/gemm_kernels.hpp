@@ -658,7 +658,10 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
     for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.ldb / BK3;
+  // plain rows advance by pointer increments with no K-tail select: stop at K (a multiple of 32 on this
+  // path), NOT at the padded weight stride — reading A columns K..ldb would run into the next row and,
+  // on the last row, past the buffer (0 x NaN = NaN even though the padded weights are zero).
+  const int nk = CONV ? p.ldb / BK3 : p.K / BK3;
   if constexpr (CONV) stage(0, 0); else stage_plain(0);
   stage_barrier();
 

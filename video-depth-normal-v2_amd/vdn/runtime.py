@@ -20,6 +20,7 @@ from . import _abi as abi
 from ._abi import F16, BF16, F32
 
 _TDT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
+_POISON = bool(int(__import__("os").environ.get("VDN_POISON", "0")))
 
 
 def ceil_to(x: int, m: int) -> int:
@@ -90,6 +91,8 @@ class Runtime:
         t = self._bufs.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
+            if not zero and _POISON and t.is_floating_point():
+                t.fill_(float("nan"))  # debug: any consumed-before-written element poisons the output
             self._bufs[key] = t
         return t
 
