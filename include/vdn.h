@@ -112,6 +112,10 @@ typedef struct vdn_gemm_desc {
   void* dst_lo[3];
   const void* res1_lo;
   const void* res2_lo;
+  /* conv K order: 0 = (tap, ci) ; 1 = (ci/64, tap, ci%64) — requires cC % 64 == 0. With order 1
+   * consecutive K steps read the same pixels' neighbouring taps / the two halves of one 128-byte
+   * line, so the 9x re-read of the input map is served from L2 instead of HBM.                   */
+  int32_t conv_korder;
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);

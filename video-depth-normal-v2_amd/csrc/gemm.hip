@@ -16,6 +16,7 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.W & 15) || ((uintptr_t)d.zeros & 15)) return VDN_EALIGN;
   if (d.a_mode == VDN_A_CONV3X3) {
     if ((d.cC & 7) || d.K != 9 * d.cC || d.M != d.cB * d.cOH * d.cOW) return VDN_EINVAL;
+    if (d.conv_korder && ((d.cC & 63) || d.conv_korder != 1)) return VDN_EINVAL;
     if (d.cstride != 1 && d.cstride != 2) return VDN_EUNSUPPORTED;
     if (d.cOH != (d.cH + 2 - 3) / d.cstride + 1 || d.cOW != (d.cW + 2 - 3) / d.cstride + 1) return VDN_EINVAL;
   } else if (d.a_mode == VDN_A_PLAIN) {

@@ -267,9 +267,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
     const int k = kt * BK + chunk * 8;
     if constexpr (CONV) {
       // (tap, ci) of this lane's chunk; Cin % 8 == 0 so a chunk never straddles two taps
-      const int kc = k >> 3;
-      const int tap = (int)(((float)kc + 0.5f) * inv_cin);
-      const int ci = k - tap * p.cC;
+      int tap, ci;
+      if (p.conv_korder) {  // (ci/64, tap, ci%64): one 64-channel block of one tap per K step
+        const int c64 = kt / 9;
+        tap = kt - c64 * 9;
+        ci = c64 * 64 + chunk * 8;
+        if (ci >= p.cC) tap = 9;
+      } else {
+        const int kc = k >> 3;
+        tap = (int)(((float)kc + 0.5f) * inv_cin);
+        ci = k - tap * p.cC;
+      }
       const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
@@ -419,8 +427,17 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
     int ky = 0, kx = 0, ci = 0;
     bool kok = k < p.K;
     if constexpr (CONV) {
-      const int tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
-      ci = k - tap * p.cC;
+      int tap;
+      if (p.conv_korder) {  // (ci/64, tap, half, ci%32): scalar decode, same for every lane of the step
+        const int half = kt & 1, t2 = kt >> 1;
+        const int c64 = t2 / 9;
+        tap = t2 - c64 * 9;
+        ci = c64 * 64 + half * 32 + chunk * 8;
+        if (ci >= p.cC) tap = 9;
+      } else {
+        tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
+        ci = k - tap * p.cC;
+      }
       ky = tap / 3;
       kx = tap - ky * 3;
       kok = tap < 9;
@@ -578,8 +595,17 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
     int ky = 0, kx = 0, ci = 0;
     bool kok = k < p.K;
     if constexpr (CONV) {
-      const int tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
-      ci = k - tap * p.cC;
+      int tap;
+      if (p.conv_korder) {  // (ci/64, tap, half, ci%32): scalar decode, same for every lane of the step
+        const int half = kt & 1, t2 = kt >> 1;
+        const int c64 = t2 / 9;
+        tap = t2 - c64 * 9;
+        ci = c64 * 64 + half * 32 + chunk * 8;
+        if (ci >= p.cC) tap = 9;
+      } else {
+        tap = (int)(((float)(k >> 3) + 0.5f) * inv_cin);
+        ci = k - tap * p.cC;
+      }
       ky = tap / 3;
       kx = tap - ky * 3;
       kok = tap < 9;

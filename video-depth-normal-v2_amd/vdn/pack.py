@@ -43,10 +43,22 @@ def conv1x1(w: torch.Tensor, half) -> torch.Tensor:
     return _pad_k(w.detach().float().reshape(w.shape[0], w.shape[1]), half)
 
 
+def conv_korder(ci: int) -> int:
+    """K order of the implicit-GEMM 3x3 conv: 1 = (ci/64, tap, ci%64) when Cin is a multiple of 64 (consecutive
+    K steps then re-read the same 128-byte lines: L2 instead of HBM), else 0 = (tap, ci)."""
+    return 1 if ci % 64 == 0 else 0
+
+
 def conv3x3(w: torch.Tensor, half) -> torch.Tensor:
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3 and ci % 8 == 0, w.shape
-    return _pad_k(w.detach().float().permute(0, 2, 3, 1).reshape(co, 9 * ci), half)
+    wf = w.detach().float()
+    if conv_korder(ci):
+        # [co, c64, 64, ky, kx] -> [co, c64, ky, kx, 64]
+        wk = wf.reshape(co, ci // 64, 64, 3, 3).permute(0, 1, 3, 4, 2).reshape(co, 9 * ci)
+    else:
+        wk = wf.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    return _pad_k(wk, half)
 
 
 def conv_transpose(w: torch.Tensor, b: torch.Tensor, half) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -168,6 +168,7 @@ class Runtime:
             d.cB, d.cH, d.cW, d.cC = conv["B"], conv["H"], conv["W"], conv["C"]
             d.cOH, d.cOW, d.cstride = conv["OH"], conv["OW"], conv["stride"]
             d.lda = conv["C"]
+            d.conv_korder = conv.get("korder", 1 if conv["C"] % 64 == 0 else 0)  # must match pack.conv3x3
         else:
             d.a_mode = abi.A_PLAIN
             d.lda = lda if lda is not None else K
