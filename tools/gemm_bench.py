@@ -11,9 +11,14 @@ split = "--single" not in sys.argv
 rt = Runtime(torch.device("cuda:0"), torch.float16, split=split)
 B = 8
 M = B * 1370
-shapes = [("qkv", M, 3072, 1024, {}), ("proj", M, 1024, 1024, {}), ("fc1", M, 4096, 1024, dict(act=_abi.ACT_GELU)), ("fc2", M, 1024, 4096, {}),
-          ("mem_kv", B * 1369, 2048, 1024, {}), ("conv256@148", B * 148 * 148, 256, 2304, dict(conv=(148, 256))),
-          ("conv256@296->128", B * 296 * 296, 128, 2304, dict(conv=(296, 256)))]
+if "--kscan" in sys.argv:
+    shapes = [(f"N1024_K{k}", M, 1024, k, {}) for k in (32, 64, 128, 256, 512, 1024, 2048, 4096)] + \
+             [(f"N4096_K{k}", M, 4096, k, dict(act=_abi.ACT_GELU)) for k in (32, 256, 1024)] + \
+             [(f"N3072h_K{k}", M, 3072, k, {}) for k in (32, 1024)]
+else:
+  shapes = [("qkv", M, 3072, 1024, {}), ("proj", M, 1024, 1024, {}), ("fc1", M, 4096, 1024, dict(act=_abi.ACT_GELU)), ("fc2", M, 1024, 4096, {}),
+            ("mem_kv", B * 1369, 2048, 1024, {}), ("conv256@148", B * 148 * 148, 256, 2304, dict(conv=(148, 256))),
+            ("conv256@296->128", B * 296 * 296, 128, 2304, dict(conv=(296, 256)))]
 torch.manual_seed(0)
 res = []
 for name, m, n, k, opt in shapes:

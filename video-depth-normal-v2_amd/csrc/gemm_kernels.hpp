@@ -22,167 +22,171 @@ namespace vdn_gemm_impl {
 
 constexpr int BK = 64;
 
-// Fused fp32 epilogue straight from the accumulators. The MFMAs are issued with the WEIGHT fragment
-// as the A operand and the activation fragment as B, so the accumulator tile is C^T:
+// ---------------------------------------------------------------------------------------------
+// Fused fp32 epilogue. The MFMAs are issued with the WEIGHT fragment as the A operand and the
+// activation fragment as B, so an accumulator tile is C^T:
 //   acc[i][j][e]  ->  C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + 4 (lane >> 4) + e]
-// i.e. every lane owns 4 CONSECUTIVE output columns of one row: bias / gamma / table / residual
-// operands are single 16-byte loads and the result leaves as one 8- or 16-byte store per plane,
-// with no LDS round trip and no barrier (all 8 waves work on their own tile in parallel).
-// STORE is the vdn_store mode (compile-time in the big kernel, dispatched at run time elsewhere).
-template <int DT, int TM, int TN, int STORE>
-__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
+// i.e. a lane always holds 4 CONSECUTIVE output columns of one row. emit4() finishes one such group:
+// bias / row-add / activation / LayerScale / pos-embed table / residuals as single 16-byte loads,
+// then one 8- or 16-byte store per plane in the layout the consumer reads (plain rows, per-head
+// Q/K/V^T with RoPE, pixel-shuffle, GEGLU). `b` is the group 16 columns to the right (the GEGLU gate /
+// the RoPE imaginary parts, which the weight packing put there).
+template <int DT, int STORE>
+__device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x4 a, f32x4 b) {
   using H = Half<DT>;
   using T = typename H::T;
+  if (m >= p.M || n >= p.N) return;
+  if constexpr (STORE == VDN_ST_PLAIN || STORE == VDN_ST_CONVT) {
+    if (p.bias) a += *(const f32x4*)(p.bias + n);
+    if (p.rowadd) a += p.rowadd[m];
+    if (p.act == VDN_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = gelu_fast(a[e]);
+    } else if (p.act == VDN_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+    }
+    if (p.gamma) a *= *(const f32x4*)(p.gamma + n);
+    if (p.tab) a += *(const f32x4*)(p.tab + (size_t)(m % p.tab_mod + p.tab_off) * p.N + n);
+    if (p.res1) {
+      a += load4_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n);
+      if (p.res1_lo) a += load4_as_float(p.res1_lo, p.res1_dt, (size_t)m * p.ldr1 + n);
+    }
+    if (p.res2) {
+      a += load4_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n);
+      if (p.res2_lo) a += load4_as_float(p.res2_lo, p.res2_dt, (size_t)m * p.ldr2 + n);
+    }
+    size_t o;
+    if constexpr (STORE == VDN_ST_CONVT) {
+      const int hw = p.cH * p.cW;
+      const int cb = m / hw, rem = m - cb * hw;
+      const int cy = rem / p.cW, cx = rem - cy * p.cW;
+      const int kk = n / p.cout, co = n - kk * p.cout;  // cout % 4 == 0: the 4 columns share a tap
+      const int ky = kk / p.ck, kx = kk - ky * p.ck;
+      o = ((((size_t)cb * (p.cH * p.ck) + cy * p.ck + ky) * (p.cW * p.ck)) + cx * p.ck + kx) * p.cout + co;
+    } else {
+      o = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc + n;
+    }
+    if (p.out_dt == VDN_F32) {
+      *(f32x4*)((float*)p.out + o) = a;
+    } else if (p.out_lo) {
+      typename H::V4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+      *(typename H::V4*)((T*)p.out + o) = h;
+      *(typename H::V4*)((T*)p.out_lo + o) = l;
+    } else {
+      typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
+      *(typename H::V4*)((T*)p.out + o) = h;
+    }
+  } else if constexpr (STORE == VDN_ST_GEGLU) {
+    // packed columns: 16-wide blocks alternate [h | gate]
+    if ((n & 16) || n + 16 >= p.N) return;
+    if (p.bias) { a += *(const f32x4*)(p.bias + n); b += *(const f32x4*)(p.bias + n + 16); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = a[e] * gelu_fast(b[e]);
+    const size_t o = (size_t)m * p.ldc + ((n >> 5) << 4) + (n & 15);
+    if (p.out_dt == VDN_F32) {
+      *(f32x4*)((float*)p.out + o) = a;
+    } else if (p.out_lo) {
+      typename H::V4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+      *(typename H::V4*)((T*)p.out + o) = h;
+      *(typename H::V4*)((T*)p.out_lo + o) = l;
+    } else {
+      typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
+      *(typename H::V4*)((T*)p.out + o) = h;
+    }
+  } else {  // VDN_ST_HEADS
+    const int hc = p.heads * 64;
+    const int bt = m / p.tokens, tl = m - bt * p.tokens;
+    const int tk = tl + p.tok_off;
+    const int split = n / hc;
+    const int head = (n - split * hc) >> 6, e0 = n & 63;
+    const size_t hb = (size_t)bt * p.heads + head;
+    T* dst = (T*)p.dst[split];
+    T* dlo = (T*)p.dst_lo[split];
+    if (p.bias) a += *(const f32x4*)(p.bias + n);
+    if (p.rope[split]) {
+      if (e0 & 16) return;  // imaginary group: consumed together with its real partner
+      if (p.bias) b += *(const f32x4*)(p.bias + n + 16);
+      const int pi = ((e0 >> 5) << 4) + (e0 & 15);  // first of 4 consecutive pair indices
+      const float* cs = p.rope_cs + (size_t)(tl % p.rope_mod) * 64 + 2 * pi;
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float cc = cs[2 * e], ss = cs[2 * e + 1];
+        o8[2 * e] = a[e] * cc - b[e] * ss;
+        o8[2 * e + 1] = a[e] * ss + b[e] * cc;
+      }
+      if (p.transposed[split]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) store_half(dst, dlo, (hb * 64 + 2 * pi + e) * p.tpad + tk, o8[e]);
+      } else {
+        const size_t o = (hb * p.tpad + tk) * 64 + 2 * pi;
+        typename H::V8 h8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (dlo) { T x0, x1; split_rtz(o8[e], x0, x1); h8[e] = x0; l8[e] = x1; }
+          else h8[e] = (T)o8[e];
+        }
+        *(typename H::V8*)(dst + o) = h8;
+        if (dlo) *(typename H::V8*)(dlo + o) = l8;
+      }
+      return;
+    }
+    if (p.transposed[split]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) store_half(dst, dlo, (hb * 64 + e0 + e) * p.tpad + tk, a[e]);
+    } else {
+      const size_t o = (hb * p.tpad + tk) * 64 + e0;
+      typename H::V4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (dlo) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+        else h[e] = (T)a[e];
+      }
+      *(typename H::V4*)(dst + o) = h;
+      if (dlo) *(typename H::V4*)(dlo + o) = l;
+    }
+  }
+}
+
+// Epilogue straight from registers (4-wave kernels): a store instruction covers 16 rows x 64 (f32) or
+// 32 (half) bytes.
+template <int DT, int TM, int TN, int STORE>
+__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      emit4<DT, STORE>(p, mw + i * 16 + fr, nw + j * 16 + fq * 4, acc[i][j], acc[i][j + 1 < TN ? j + 1 : j]);
+}
+
+// Epilogue through a wave-private LDS transpose (8-wave kernels, wave tile 16 TM x 64): each 16-row slab of
+// the wave's tile is written to LDS in the accumulator layout and read back so that 16 consecutive lanes
+// own one ROW's 64 columns: a store instruction then covers 4 rows x 256 contiguous bytes (f32) or
+// 128 bytes per plane (half) instead of 16 rows x 64/32 bytes. No block barrier: the region is private
+// to the wave and a wave's LDS operations execute in order.
+template <int DT, int TM, int STORE>
+__device__ __forceinline__ void epilogue_wave_lds(f32x4 (&acc)[TM][4], const vdn_gemm_desc& p, float* wl, int mw, int nw,
+                                                  int lane) {
+  constexpr int LDW = 68;  // padded row (floats)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rr = lane >> 4, cc = (lane & 15) * 4;
+#pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = mw + i * 16 + fr;
-    if (m >= p.M) continue;
-    if constexpr (STORE == VDN_ST_PLAIN || STORE == VDN_ST_CONVT) {
-      const float radd = p.rowadd ? p.rowadd[m] : 0.f;
-      const float* tabr = p.tab ? p.tab + (size_t)(m % p.tab_mod + p.tab_off) * p.N : nullptr;
-      size_t obase;
-      if constexpr (STORE == VDN_ST_CONVT) {
-        const int hw = p.cH * p.cW;
-        const int cb = m / hw, rem = m - cb * hw;
-        const int cy = rem / p.cW, cx = rem - cy * p.cW;
-        obase = ((size_t)cb * (p.cH * p.ck) + cy * p.ck) * (p.cW * p.ck) + cx * p.ck;  // pixel index of tap (0,0)
-      } else {
-        obase = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc;
-      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = nw + j * 16 + fq * 4;
-        if (n >= p.N) continue;
-        f32x4 a = acc[i][j];
-        if (p.bias) a += *(const f32x4*)(p.bias + n);
-        a += radd;
-        if (p.act == VDN_ACT_GELU) {
+    for (int j = 0; j < 4; ++j) *(f32x4*)(wl + fr * LDW + j * 16 + fq * 4) = acc[i][j];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] = gelu_fast(a[e]);
-        } else if (p.act == VDN_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
-        }
-        if (p.gamma) a *= *(const f32x4*)(p.gamma + n);
-        if (tabr) a += *(const f32x4*)(tabr + n);
-        if (p.res1) {
-          a += load4_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n);
-          if (p.res1_lo) a += load4_as_float(p.res1_lo, p.res1_dt, (size_t)m * p.ldr1 + n);
-        }
-        if (p.res2) {
-          a += load4_as_float(p.res2, p.res2_dt, (size_t)m * p.ldr2 + n);
-          if (p.res2_lo) a += load4_as_float(p.res2_lo, p.res2_dt, (size_t)m * p.ldr2 + n);
-        }
-        size_t o;
-        if constexpr (STORE == VDN_ST_CONVT) {
-          const int kk = n / p.cout, co = n - kk * p.cout;  // cout % 4 == 0: the 4 columns share a tap
-          const int ky = kk / p.ck, kx = kk - ky * p.ck;
-          o = (obase + (size_t)ky * (p.cW * p.ck) + kx) * p.cout + co;
-        } else {
-          o = obase + n;
-        }
-        if (p.out_dt == VDN_F32) {
-          *(f32x4*)((float*)p.out + o) = a;
-        } else if (p.out_lo) {
-          typename H::V4 h, l;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
-          *(typename H::V4*)((T*)p.out + o) = h;
-          *(typename H::V4*)((T*)p.out_lo + o) = l;
-        } else {
-          typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
-          *(typename H::V4*)((T*)p.out + o) = h;
-        }
-      }
-    } else if constexpr (STORE == VDN_ST_GEGLU) {
-      // packed columns: 16-wide blocks alternate [h | gate]; the pair sits in tiles (j, j+1) of this lane
-#pragma unroll
-      for (int j = 0; j + 1 < TN; j += 2) {
-        const int nh = nw + j * 16 + fq * 4;
-        if (nh + 16 >= p.N) continue;
-        f32x4 hv = acc[i][j], gv = acc[i][j + 1];
-        if (p.bias) { hv += *(const f32x4*)(p.bias + nh); gv += *(const f32x4*)(p.bias + nh + 16); }
-        f32x4 a;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = hv[e] * gelu_fast(gv[e]);
-        const size_t o = (size_t)m * p.ldc + ((nw + j * 16) >> 1) + fq * 4;
-        if (p.out_dt == VDN_F32) {
-          *(f32x4*)((float*)p.out + o) = a;
-        } else if (p.out_lo) {
-          typename H::V4 h, l;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
-          *(typename H::V4*)((T*)p.out + o) = h;
-          *(typename H::V4*)((T*)p.out_lo + o) = l;
-        } else {
-          typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
-          *(typename H::V4*)((T*)p.out + o) = h;
-        }
-      }
-    } else {  // VDN_ST_HEADS
-      const int hc = p.heads * 64;
-      const int bt = m / p.tokens, tl = m - bt * p.tokens;
-      const int tk = tl + p.tok_off;
-      const float* cs = p.rope_cs ? p.rope_cs + (size_t)(tl % p.rope_mod) * 64 : nullptr;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = nw + j * 16 + fq * 4;
-        if (n >= p.N) continue;
-        const int split = n / hc;
-        const int head = (n - split * hc) >> 6, e0 = n & 63;
-        const size_t hb = (size_t)bt * p.heads + head;
-        T* dst = (T*)p.dst[split];
-        T* dlo = (T*)p.dst_lo[split];
-        f32x4 a = acc[i][j];
-        if (p.bias) a += *(const f32x4*)(p.bias + n);
-        if (p.rope[split]) {
-          if (e0 & 16) continue;  // imaginary tile: consumed together with its real partner (tile j-1)
-          if constexpr (TN > 1) {
-            if (j + 1 < TN) {
-              f32x4 b = acc[i][j + 1 < TN ? j + 1 : j];
-              if (p.bias) b += *(const f32x4*)(p.bias + n + 16);
-              const int pi = ((e0 >> 5) << 4) + (e0 & 15);  // first of 4 consecutive pair indices
-              float o8[8];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float cc = cs[2 * (pi + e)], ss = cs[2 * (pi + e) + 1];
-                o8[2 * e] = a[e] * cc - b[e] * ss;
-                o8[2 * e + 1] = a[e] * ss + b[e] * cc;
-              }
-              if (p.transposed[split]) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) store_half(dst, dlo, (hb * 64 + 2 * pi + e) * p.tpad + tk, o8[e]);
-              } else {
-                const size_t o = (hb * p.tpad + tk) * 64 + 2 * pi;
-                typename H::V8 h8, l8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  if (dlo) { T x0, x1; split_rtz(o8[e], x0, x1); h8[e] = x0; l8[e] = x1; }
-                  else h8[e] = (T)o8[e];
-                }
-                *(typename H::V8*)(dst + o) = h8;
-                if (dlo) *(typename H::V8*)(dlo + o) = l8;
-              }
-            }
-          }
-          continue;
-        }
-        if (p.transposed[split]) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) store_half(dst, dlo, (hb * 64 + e0 + e) * p.tpad + tk, a[e]);
-        } else {
-          const size_t o = (hb * p.tpad + tk) * 64 + e0;
-          typename H::V4 h, l;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (dlo) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
-            else h[e] = (T)a[e];
-          }
-          *(typename H::V4*)(dst + o) = h;
-          if (dlo) *(typename H::V4*)(dlo + o) = l;
-        }
-      }
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 4 + rr;
+      const f32x4 a = *(const f32x4*)(wl + row * LDW + cc);
+      f32x4 b = a;
+      if constexpr (STORE == VDN_ST_GEGLU || STORE == VDN_ST_HEADS) b = *(const f32x4*)(wl + row * LDW + ((cc + 16) & 63));
+      emit4<DT, STORE>(p, mw + i * 16 + row, nw + cc, a, b);
     }
   }
 }
@@ -731,7 +735,8 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
   step(nk - 1, std::false_type{});
 
-  epilogue_regs<DT, TMW, TNW, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  // the K loop ended with a barrier: the staging buffers are free, each wave takes a private 4.25 KiB slab
+  epilogue_wave_lds<DT, TMW, STORE>(acc, p, (float*)(smem + wave * 4352), m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
 template <int DT, int BM, int BN, int WM, int WN>
