@@ -735,8 +735,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
   step(nk - 1, std::false_type{});
 
-  // the K loop ended with a barrier: the staging buffers are free, each wave takes a private 4.25 KiB slab
-  epilogue_wave_lds<DT, TMW, STORE>(acc, p, (float*)(smem + wave * 4352), m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  // (epilogue_wave_lds — row-contiguous stores through a wave-private LDS transpose — measured 8 % SLOWER on
+  //  the whole forward in a same-box A/B although faster on isolated plain-store GEMMs; kept for reference)
+  epilogue_regs<DT, TMW, TNW, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
 template <int DT, int BM, int BN, int WM, int WN>
