@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
 // 150-200 flop per byte, which is what the ~25 B/clk/CU global->LDS path can feed (the 128 x 128
 // tile needs 43 B/clk at full MFMA rate and stalls on it — profiles/r01_*).
 // BM in {128, 192, 256} is chosen per launch so that the tile count fills the 256 CUs evenly.
-template <int DT, int AMODE, int BM, int STORE>
+template <int DT, int AMODE, int BM, int STORE, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p) {
   using H = Half<DT>;
   using V8 = typename H::V8;
@@ -692,8 +692,10 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   // path), NOT at the padded weight stride — reading A columns K..ldb would run into the next row and,
   // on the last row, past the buffer (0 x NaN = NaN even though the padded weights are zero).
   const int nk = CONV ? p.ldb / BK3 : p.K / BK3;
-  if constexpr (CONV) stage(0, 0); else stage_plain(0);
-  stage_barrier();
+  if constexpr (!PIPE) {
+    if constexpr (CONV) stage(0, 0); else stage_plain(0);
+    stage_barrier();
+  }
 
   // one K step on stage `cur`; STAGED: the next stage's DMA is issued inside the step
   auto step = [&](int kt, auto staged) {
@@ -732,8 +734,77 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
         }
     stage_barrier();
   };
-  for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
-  step(nk - 1, std::false_type{});
+  if constexpr (!PIPE) {
+    for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
+    step(nk - 1, std::false_type{});
+  }
+
+
+  // ---- phase-shifted pipeline (PIPE): the stage barrier sits in the MIDDLE of a K step.
+  //   phase 1: MFMAs of A-half 0 (operands already in registers) || ds_read A-half 1 of this stage
+  //   [own LDS reads + own DMA complete; barrier]  -> this stage's buffer is free, next stage has landed
+  //   phase 2: issue DMA for stage k+2 || ds_read W and A-half 0 of stage k+1 || MFMAs of A-half 1
+  // so the matrix pipe always has register-resident work while DMA issue, LDS latency and the barrier
+  // pass (the plain loop idles ~1000 cycles per step on them). Costs a second W fragment set.
+  if constexpr (PIPE) {
+    auto issue = [&](int buf, int kt) {
+      if constexpr (CONV) stage(buf, kt); else stage_plain(buf);
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    stage_barrier();
+    V8 b0h[TNW], b0l[TNW], b1h[TNW], b1l[TNW], a0h[HALF], a0l[HALF], a1h[HALF], a1l[HALF];
+    auto read_b = [&](const char* s0, V8 (&h)[TNW], V8 (&l)[TNW]) {
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) {
+        h[t] = *(const V8*)(s0 + b_off[t]);
+        l[t] = *(const V8*)(s0 + W_TILE + b_off[t]);
+      }
+    };
+    auto read_a = [&](const char* s0, int hf, V8 (&h)[HALF], V8 (&l)[HALF]) {
+#pragma unroll
+      for (int t = 0; t < HALF; ++t) {
+        h[t] = *(const V8*)(s0 + a_off[hf * HALF + t]);
+        l[t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
+        if constexpr (RELU_A) { h[t] = relu8(h[t]); l[t] = relu8(l[t]); }
+      }
+    };
+    auto mma = [&](int hf, V8 (&ah_)[HALF], V8 (&al_)[HALF], V8 (&bh_)[TNW], V8 (&bl_)[TNW]) {
+#pragma unroll
+      for (int i = 0; i < HALF; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          f32x4 c = acc[hf * HALF + i][j];
+          c = H::mfma16(bh_[j], al_[i], c);
+          c = H::mfma16(bl_[j], ah_[i], c);
+          c = H::mfma16(bh_[j], ah_[i], c);
+          acc[hf * HALF + i][j] = c;
+        }
+    };
+    read_b(smem, b0h, b0l);
+    read_a(smem, 0, a0h, a0l);
+    auto pstep = [&](int kt, V8 (&bch)[TNW], V8 (&bcl)[TNW], V8 (&bnh)[TNW], V8 (&bnl)[TNW]) {
+      const int cur = kt & 1;
+      const char* sc = smem + cur * STAGE;
+      const char* sn = smem + (cur ^ 1) * STAGE;
+      read_a(sc, 1, a1h, a1l);
+      mma(0, a0h, a0l, bch, bcl);
+      stage_barrier();
+      if (kt + 2 < nk) issue(cur, kt + 2);
+      if (kt + 1 < nk) {
+        read_b(sn, bnh, bnl);
+        read_a(sn, 0, a0h, a0l);
+      }
+      mma(1, a1h, a1l, bch, bcl);
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      pstep(kt, b0h, b0l, b1h, b1l);
+      pstep(kt + 1, b1h, b1l, b0h, b0l);
+    }
+    if (kt < nk) pstep(kt, b0h, b0l, b1h, b1l);
+    stage_barrier();
+  }
 
   // (epilogue_wave_lds — row-contiguous stores through a wave-private LDS transpose — measured 8 % SLOWER on
   //  the whole forward in a same-box A/B although faster on isolated plain-store GEMMs; kept for reference)
@@ -777,17 +848,30 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + 255) / 256);
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * 256 * 64);
   const dim3 g(tiles), b(512);
+  static const bool no_pipe = getenv("VDN_GEMM_NOPIPE") != nullptr;
+  constexpr bool CAN_PIPE = BM <= 192;  // BM = 256 has no registers for the second W fragment set
+  const bool pipe = CAN_PIPE && !no_pipe;
+#define VDN_LAUNCH_BIG(AM, ST)                                                                          \
+  do {                                                                                                  \
+    if constexpr (CAN_PIPE && (AM == 0 || BM == 128)) { /* conv + BM=192 would spill */                \
+      if (pipe) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, AM, BM, ST, true>), g, b, lds, s, d);        \
+      else hipLaunchKernelGGL((gemm_x3_big_kernel<DT, AM, BM, ST, false>), g, b, lds, s, d);            \
+    } else {                                                                                            \
+      hipLaunchKernelGGL((gemm_x3_big_kernel<DT, AM, BM, ST, false>), g, b, lds, s, d);                 \
+    }                                                                                                   \
+  } while (0)
   if (d.a_mode == VDN_A_CONV3X3) {  // convolutions always store plain NHWC rows
-    if (d.relu_a) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, BM, VDN_ST_PLAIN>), g, b, lds, s, d);
-    else hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 1, BM, VDN_ST_PLAIN>), g, b, lds, s, d);
+    if (d.relu_a) VDN_LAUNCH_BIG(2, VDN_ST_PLAIN);
+    else VDN_LAUNCH_BIG(1, VDN_ST_PLAIN);
   } else {
     switch (d.store) {
-      case VDN_ST_PLAIN: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_PLAIN>), g, b, lds, s, d); break;
-      case VDN_ST_CONVT: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_CONVT>), g, b, lds, s, d); break;
-      case VDN_ST_GEGLU: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_GEGLU>), g, b, lds, s, d); break;
-      default: hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, BM, VDN_ST_HEADS>), g, b, lds, s, d); break;
+      case VDN_ST_PLAIN: VDN_LAUNCH_BIG(0, VDN_ST_PLAIN); break;
+      case VDN_ST_CONVT: VDN_LAUNCH_BIG(0, VDN_ST_CONVT); break;
+      case VDN_ST_GEGLU: VDN_LAUNCH_BIG(0, VDN_ST_GEGLU); break;
+      default: VDN_LAUNCH_BIG(0, VDN_ST_HEADS); break;
     }
   }
+#undef VDN_LAUNCH_BIG
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
