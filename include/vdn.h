@@ -197,6 +197,12 @@ int vdn_mask_down2(const float* in, float* out, int B, int H, int W, int OH, int
 int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const float* w, const float* bias,
                 vdn_stream stream);
 
+/* y(half planes) = x(f32) + tab[(row / tab_div) % tab_mod]: the sinusoidal frame-position add of
+ * motion_module.py:211 applied to a window assembled from cached (already LayerNorm-ed) states in the
+ * streaming mode (video_depth_stream.py:133-144, motion_module.py:255-266).                        */
+int vdn_addtab_cast(int dt, const float* x, const float* tab, int tab_div, int tab_mod, void* y, void* y_lo,
+                    size_t rows, int C, vdn_stream stream);
+
 /* misc */
 int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);
 size_t vdn_sizeof_gemm_desc(void);      /* layout probes for FFI bindings */

@@ -182,3 +182,26 @@ def test_window_sharded_driver_single_rank():
     d0, _ = model.infer_video_depth(frames, 24, input_size=140)
     d1, _ = infer_video_depth_sharded(model, frames, 24, input_size=140)
     assert np.allclose(d0, d1, rtol=1e-5, atol=1e-6)
+
+
+def test_streaming_mode_against_reference_fixture():
+    """infer_video_depth_one semantics: 14 frames, window slides after frame 10 (video_depth_stream.py:155-158)."""
+    from oracle import ref_cpu as O
+    g = np.load(os.path.join(GOLD, "S_vits_266.npz"))
+    _, n, H, W, _, _ = [int(v) for v in g["meta"]]
+    model = _product("B", "vits")
+    model.reset_stream()
+    x = inputs(n, H, W)
+    st = O.StreamState()
+    sd = synth_sd("B", "vits")
+    for t in range(n):
+        pre = model.stream_step(x[t][None, None].cuda(), _pre_relu=True).cpu()
+        if f"pre_{t}" in g.files:
+            e = rel_l2(torch.relu(pre), np.maximum(g[f"pre_{t}"], 0))
+            print(f"[S_vits_266] frame {t}: vs reference fixture post-ReLU {e:.2e}")
+            assert e < TOL
+        if t < 3:
+            with torch.no_grad():
+                ref = O.video_depth_stream_step(sd, x[t][None, None], st, "vits", pre_relu=True)
+            assert rel_l2(torch.relu(pre), torch.relu(ref)) < TOL
+    assert len(model._stream["cache"]) == 42

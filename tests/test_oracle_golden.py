@@ -84,3 +84,17 @@ def test_oracle_host_pieces():
     for (h, w) in [(224, 224), (392, 518), (266, 266)]:
         out = O.interpolate_pos_encoding(pe, (h // 14) * (w // 14), h, w)
         assert rel_l2(out.reshape(-1)[sample_idx(out.numel(), 512)], g[f"pos_{h}x{w}_samp"]) < 1e-6
+
+
+def test_oracle_streaming_mode():
+    g = np.load(os.path.join(GOLD, "S_vits_266.npz"))
+    _, n, H, W, _, _ = [int(v) for v in g["meta"]]
+    sd = synth_sd("B", "vits")
+    x = inputs(n, H, W)
+    st = O.StreamState()
+    with torch.no_grad():
+        for t in range(n):
+            pre = O.video_depth_stream_step(sd, x[t][None, None], st, "vits", pre_relu=True)
+            if f"pre_{t}" in g.files:
+                assert rel_l2(pre, g[f"pre_{t}"]) < TOL
+    assert len(st.frame_cache_list) == 42 and st.frame_id_list[0] == 0

@@ -197,6 +197,51 @@ def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str):
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
+def gen_stream(enc: str, H: int, W: int, n: int, keep: list, name: str):
+    """video_depth_stream.infer_video_depth_one semantics: feed pre-processed frames through
+    forward_features/forward_depth with the reference's own cache bookkeeping (video_depth_stream.py:76-160)."""
+    from video_depth_anything.video_depth_stream import VideoDepthAnything as VDS, INFER_LEN
+    from oracle import ref_cpu as O
+    cfg = O.MODEL_CONFIGS[enc]
+    torch.manual_seed(0)
+    model = VDS(**cfg).eval()
+    sd, _ = load_synth(model)
+    x = make_inputs(n, H, W)
+    hook = PreRelu(model.head.scratch.output_conv2[2])
+    st = O.StreamState()
+    out = {"meta": np.array([1, n, H, W, 1, SEED])}
+    worst = 0.0
+    for t in range(n):
+        cur = x[t][None, None]
+        # the body of infer_video_depth_one after the transform (the cv2 resize is identity-sized here)
+        model.id += 1
+        with torch.no_grad():
+            feat = model.forward_features(cur)
+            if not model.frame_cache_list:
+                depth, cache = model.forward_depth(feat, cur.shape)
+                model.frame_cache_list = [cache] * INFER_LEN
+                model.frame_id_list.extend([0] * (INFER_LEN - 1))
+            else:
+                cur_list = model.frame_cache_list[0:2] + model.frame_cache_list[-INFER_LEN + 3:]
+                cur_cache = [torch.cat([h[i] for h in cur_list], dim=1) for i in range(len(cur_list[0]))]
+                depth, cache = model.forward_depth(feat, cur.shape, cached_hidden_state_list=cur_cache)
+                model.frame_cache_list.append(cache)
+        model.frame_id_list.append(model.id)
+        if model.id + INFER_LEN > model.gap + 1:
+            del model.frame_id_list[1]
+            del model.frame_cache_list[1]
+        pre = hook.val[-1][-1, 0]
+        with torch.no_grad():
+            mine = O.video_depth_stream_step(sd, cur, st, enc, pre_relu=True)
+        e = relerr(mine, pre)
+        worst = max(worst, e)
+        print(f"[stream {name}] frame {t}: cache len {len(model.frame_cache_list)} pre-ReLU mean {pre.mean():.4f} oracle rel err {e:.2e}")
+        if t in keep:
+            out[f"pre_{t}"] = pre.numpy()
+    assert worst <= 1e-5, worst
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+
+
 def gen_host():
     """G7/G8: Resize.get_size table, scale/shift + blend, pos-embed interpolation, stitcher."""
     from depth_anything_v2.util.transform import Resize
@@ -295,6 +340,7 @@ JOBS = {
     "A_vits_b2_266": lambda: gen_A("vits", 266, 266, 2, 3, [0, 1, 2], 1, "A_vits_b2_266"),
     "B_vits_518": lambda: gen_B("vits", 518, 518, 32, [0, 13, 31], 2, "B_vits_518"),
     "B_vits_392x518": lambda: gen_B("vits", 392, 518, 8, [0, 7], 2, "B_vits_392x518"),
+    "S_vits_266": lambda: gen_stream("vits", 266, 266, 14, [0, 1, 11, 13], "S_vits_266"),
     "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 2, [0, 1], 4, "A_vitl_518"),
     "B_vitl_518": lambda: gen_B("vitl", 518, 518, 4, [0, 3], 4, "B_vitl_518"),
 }

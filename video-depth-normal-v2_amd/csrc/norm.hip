@@ -197,6 +197,29 @@ __global__ void add_vec_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+template <int DT>
+__global__ void addtab_cast_kernel(const float* __restrict__ x, const float* __restrict__ tab, int tab_div, int tab_mod,
+                                   typename Half<DT>::T* __restrict__ y, typename Half<DT>::T* __restrict__ yl, size_t rows,
+                                   int C) {
+  using T = typename Half<DT>::T;
+  const int cv = C >> 2;
+  const size_t n4 = rows * cv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / cv;
+    const int c = (int)(i - row * cv) * 4;
+    f32x4 a = *(const f32x4*)(x + row * C + c);
+    if (tab) a += *(const f32x4*)(tab + (size_t)((row / tab_div) % tab_mod) * C + c);
+    typename Half<DT>::V4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (yl) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+      else h[e] = (T)a[e];
+    }
+    *(typename Half<DT>::V4*)(y + row * C + c) = h;
+    if (yl) *(typename Half<DT>::V4*)(yl + row * C + c) = l;
+  }
+}
+
 __global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restrict__ y, int ydt, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_from_float(y, ydt, i, load_as_float(x, xdt, i));
@@ -271,6 +294,26 @@ extern "C" int vdn_add_vec(const float* x, const float* vec, float alpha, float*
   const size_t n4 = (size_t)rows * C / 4;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(add_vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, vec, alpha, y, n4, C);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_addtab_cast(int dt, const float* x, const float* tab, int tab_div, int tab_mod, void* y, void* y_lo,
+                               size_t rows, int C, vdn_stream stream) {
+  if (!x || !y || rows == 0 || C <= 0 || (tab && (tab_div <= 0 || tab_mod <= 0))) return VDN_EINVAL;
+  if (C & 3) return VDN_EALIGN;
+  const size_t n4 = rows * (C >> 2);
+  const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (!tab) { tab_div = 1; tab_mod = 1; }
+  if (dt == VDN_F16)
+    hipLaunchKernelGGL(addtab_cast_kernel<VDN_F16>, dim3(blocks), dim3(256), 0, s, x, tab, tab_div, tab_mod, (_Float16*)y,
+                       (_Float16*)y_lo, rows, C);
+  else if (dt == VDN_BF16)
+    hipLaunchKernelGGL(addtab_cast_kernel<VDN_BF16>, dim3(blocks), dim3(256), 0, s, x, tab, tab_div, tab_mod, (__bf16*)y,
+                       (__bf16*)y_lo, rows, C);
+  else
+    return VDN_EUNSUPPORTED;
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }

@@ -73,6 +73,7 @@ EXPORTS = {
     "vdn_mask_down1": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_mask_down2": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_dwconv7": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
+    "vdn_addtab_cast": (C.c_int, [C.c_int, fp, fp, C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]),
     "vdn_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_size_t, vp]),
     "vdn_sizeof_gemm_desc": (C.c_size_t, []),
     "vdn_offsetof_gemm_zeros": (C.c_size_t, []),

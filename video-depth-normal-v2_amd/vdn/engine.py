@@ -173,6 +173,40 @@ class TemporalEngine:
         """x half [(b f) * HW, c] (NHWC frames) -> same shape."""
         return self.out(self.core(self.gn(x, B * T, HW), B, T, HW), x, B * T * HW)
 
+    def run_stream(self, x, HW: int, cached, new_entries: list):
+        """Streaming step (video_depth_stream.py:76-160, motion_module.py:255-277): x is ONE frame
+        [HW, c]. `cached` is None for the first frame (attention over the frame itself) or a list, per
+        attention block, of the 31 cached LayerNorm outputs (f32 [HW, c], oldest first); the new frame's
+        states are appended to `new_entries`. Keys/values are re-projected from the cached states
+        with the position table of the current window, exactly as the reference does."""
+        from .runtime import HL
+        rt, c = self.rt, self.c
+        g = self.gn(x, 1, HW)
+        hs = rt.fbuf("ts_h", (HW, c))
+        rt.gemm(g, self.w_in, HW, c, c, bias=self.b_in, out=hs)
+        nf = rt.fbuf("ts_nf", (HW, c))
+        T = 1 if cached is None else len(cached[0]) + 1
+        seqh = rt.hbuf("ts_seq", (T * HW, c))
+        qkv = rt.hbuf("ts_qkv", (T * HW, 3 * c))
+        a = rt.hbuf("ts_a", (T * HW, c))
+        for j, at in enumerate(self.att):
+            rt.layernorm(hs, HW, c, at["nw"], at["nb"], 1e-5, out_f=nf)
+            entry = nf.clone()
+            new_entries.append(entry)
+            seq = entry if cached is None else torch.cat(list(cached[j]) + [entry], dim=0)
+            rt.addtab_cast(seq, at["pe"], HW, T, seqh, T * HW, c)
+            rt.gemm(seqh, at["wqkv"], T * HW, 3 * c, c, out=qkv)
+            rt.temporal_attn(qkv, a, 1, T, HW, c, 8, (c // 8) ** -0.5)
+            last = HL(a.hi[(T - 1) * HW:], None if a.lo is None else a.lo[(T - 1) * HW:])
+            rt.gemm(last, at["wo"], HW, c, c, bias=at["bo"], res1=hs, out=hs)
+        n = rt.hbuf("ts_n", (HW, c))
+        rt.layernorm(hs, HW, c, self.fnw, self.fnb, 1e-5, out_h=n)
+        gg = rt.hbuf("ts_gg", (HW, 4 * c))
+        rt.gemm(n, self.wg, HW, 8 * c, c, bias=self.bg, store=abi.ST_GEGLU, out=gg)
+        hh = rt.hbuf("ts_hh", (HW, c))
+        rt.gemm(gg, self.wf2, HW, c, 4 * c, bias=self.bf2, res1=hs, out=hh)
+        return self.out(hh, x, HW)
+
     def run_sharded(self, x, exch, HW: int):
         """Frame-sharded window (vdn/dist.py): x holds this rank's Tl frames. GroupNorm and proj_out run
         on the frame shard; the per-pixel core runs on all T frames of this rank's pixel shard, with one
@@ -261,7 +295,7 @@ class DPTEngine:
         return p
 
     def run(self, taps: List[torch.Tensor], Bf: int, ph: int, pw: int, T: Optional[int] = None, relu: bool = True,
-            exch=None):
+            exch=None, stream=None):
         rt, C, F, oc = self.rt, self.C, self.F, self.oc
         P = ph * pw
         pr = []
@@ -280,6 +314,9 @@ class DPTEngine:
         l3 = pr[2]
         l4 = self._conv3(pr[3], self.rs3[0], Bf, ph, pw, oc[3], oc[3], "l4", stride=2, bias=self.rs3[1])
         def tm(i, x, hw):
+            if stream is not None:  # streaming: one new frame against the cached states of 31 earlier ones
+                cached = None if stream["cached"] is None else stream["cached"][2 * i: 2 * i + 2]
+                return self.temporal[i].run_stream(x, hw, cached, stream["new"])
             if exch is not None:  # frame-sharded window: Bf == this rank's frames of ONE clip
                 return self.temporal[i].run_sharded(x, exch, hw)
             return self.temporal[i].run(x, Bf // T, T, hw)

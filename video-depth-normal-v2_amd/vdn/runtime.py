@@ -277,5 +277,9 @@ class Runtime:
     def dwconv7(self, x, y, B, H, W, Cn, w, bias):
         self._launch(abi.lib.vdn_dwconv7, x.data_ptr(), y.data_ptr(), B, H, W, Cn, w.data_ptr(), bias.data_ptr())
 
+    def addtab_cast(self, x, tab, tab_div: int, tab_mod: int, y, rows: int, Cn: int):
+        yh, yl = _hl(y)
+        self._launch(abi.lib.vdn_addtab_cast, self.dt, x.data_ptr(), self._p(tab), tab_div, tab_mod, yh.data_ptr(), yl, rows, Cn)
+
     def cast(self, x, y):
         self._launch(abi.lib.vdn_cast, x.data_ptr(), _TDT[x.dtype], y.data_ptr(), _TDT[y.dtype], x.numel())

@@ -46,6 +46,51 @@ class VideoDepthAnything(_EngineOwner):
         depth = head.run(taps, B * T, ph, pw, T=T, relu=not _pre_relu)
         return depth.reshape(B, T, H, W).clone()
 
+    # ------------------------------------------------------------------ streaming (video_depth_stream.py)
+    def reset_stream(self):
+        self._stream = None
+
+    @torch.no_grad()
+    def stream_step(self, x: torch.Tensor, _pre_relu: bool = False) -> torch.Tensor:
+        """One pre-processed frame x [1,1,3,H,W] -> depth [H,W], with the reference's cache bookkeeping
+        (video_depth_stream.py:117-118,133-158: slot 0 pinned, 31 cached frames per step, gap 41)."""
+        e = self._engines()
+        rt, enc, head = e["rt"], e["enc"], e["head"]
+        st = getattr(self, "_stream", None)
+        if st is None:
+            st = self._stream = dict(cache=[], ids=[], id=-1, gap=(INFER_LEN - OVERLAP) * 2 - 1 - (OVERLAP - INTERP_LEN))
+        st["id"] += 1
+        _, _, _, H, W = x.shape
+        xf = x.to(device=rt.device, dtype=torch.float32).reshape(1, 3, H, W).contiguous()
+        taps, _, (ph, pw) = enc.run(xf)
+        new = []
+        if not st["cache"]:
+            depth = head.run(taps, 1, ph, pw, T=1, relu=not _pre_relu, stream=dict(cached=None, new=new))
+            st["cache"] = [new] * INFER_LEN
+            st["ids"].extend([0] * (INFER_LEN - 1))
+        else:
+            cur = st["cache"][0:2] + st["cache"][-INFER_LEN + 3:]
+            cached = [[h[i] for h in cur] for i in range(len(cur[0]))]
+            depth = head.run(taps, 1, ph, pw, T=1, relu=not _pre_relu, stream=dict(cached=cached, new=new))
+            st["cache"].append(new)
+        st["ids"].append(st["id"])
+        if st["id"] + INFER_LEN > st["gap"] + 1:
+            del st["ids"][1]
+            del st["cache"][1]
+        return depth.reshape(H, W).clone()
+
+    @torch.no_grad()
+    def infer_video_depth_one(self, frame: np.ndarray, input_size: int = 518, device: str = "cuda", fp32: bool = False):
+        """RGB u8 [h,w,3] -> f32 [h,w] (video_depth_stream.py:76-160)."""
+        fh, fw = frame.shape[:2]
+        ratio = max(fh, fw) / min(fh, fw)
+        if ratio > 1.78:
+            input_size = int(input_size * 1.777 / ratio)
+            input_size = round(input_size / 14) * 14
+        x = self.preprocess_frames(frame[None], input_size)[None]
+        d = self.stream_step(x)
+        return self.resize_depth(d[None], fh, fw)[0].cpu().numpy()
+
     @torch.no_grad()
     def forward_sharded(self, x_local: torch.Tensor, group=None, _pre_relu: bool = False) -> torch.Tensor:
         """One window whose T frames are sharded over the ranks of `group` (this rank passes its
