@@ -67,20 +67,45 @@ __device__ __forceinline__ float gelu_erf(float x) {  // nn.GELU() default (exac
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// Exact-form GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32-level):
-// ~15 VALU ops instead of libm erff's ~40 — the GEMM epilogue applies it to every fc1 output.
+// Exact-form GELU, 4 values at a time, fp32-level accuracy (|error| <= 2.5e-7 on [-8, 8], i.e. the
+// rounding of the result itself; measured against float64 erf in tools/fit_gelu.py, which also produced
+// the coefficients). With t = |x|/sqrt2:  0.5(1+erf(x/sqrt2)) = 1 - 0.5 erfc(t) for x >= 0, 0.5 erfc(t) for
+// x < 0, so  gelu(x) = max(x,0) - 0.5|x| erfc(t)  with no cancellation, and erfc(t) = 2^(t Q(t)) where
+// Q(t) = log2(erfc(t))/t is smooth: a degree-7 polynomial on [0, 4.3] (minimax in the error it causes in
+// gelu); beyond 4.3 erfc < 2e-9 and t is clamped. One v_exp_f32 and 12 multiply-adds per value, written
+// on vectors so the compiler emits packed fp32 ops (v_pk_fma_f32: two values per instruction) — the fc1
+// epilogue is VALU-bound (tools/gemm_ablate.sh: 31 of 295 us per launch with the rcp+exp form before).
+// A literal operand forces the scalar v_fmaak form; a constant the compiler cannot see through lives in
+// an SGPR and lets the multiply-adds pair up as v_pk_fma_f32.
+__device__ __forceinline__ float sgpr_const(float c) { asm("" : "+s"(c)); return c; }
+__device__ __forceinline__ f32x4 gelu4(f32x4 x) {
+  const float c7 = sgpr_const(-9.663539458415471e-06f), c6 = sgpr_const(0.00011715106666088104f),
+              c5 = sgpr_const(-0.00028722305432893336f), c4 = sgpr_const(-0.0030229499097913504f),
+              c3 = sgpr_const(0.030544215813279152f), c2 = sgpr_const(-0.14973200857639313f),
+              c1 = sgpr_const(-0.9180853962898254f), c0 = sgpr_const(-1.62794029712677f),
+              kh = sgpr_const(0.70710678118654752440f);
+  f32x4 t0, t, q, e, r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t0[i] = fabsf(x[i]) * 0.70710678118654752440f;
+    t[i] = __builtin_amdgcn_fmed3f(t0[i], 0.f, 4.3f);
+    r[i] = __builtin_amdgcn_fmed3f(x[i], 0.f, 3.0e38f);
+  }
+  q = t * c7 + c6;
+  q = q * t + c5;
+  q = q * t + c4;
+  q = q * t + c3;
+  q = q * t + c2;
+  q = q * t + c1;
+  q = q * t + c0;
+  q = q * t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(q[i]);
+  return r - (t0 * kh) * e;  // 0.5|x| = t0/sqrt2
+}
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float erf_abs = fmaf(-poly, e, 1.0f);          // erf(|x|/sqrt2)
-  const float erf_s = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erf_s);
+  const f32x4 r = gelu4(f32x4{x, x, x, x});
+  return r[0];
 }
 
 // 4 consecutive values of a residual / table operand as floats (16-byte or 8-byte vector load)

@@ -36,12 +36,14 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
   using H = Half<DT>;
   using T = typename H::T;
   if (m >= p.M || n >= p.N) return;
+#if defined(VDN_ABLATE) && (VDN_ABLATE & 8)
+  if (p.M > 0) { if (a[0] + a[1] + a[2] + a[3] == 123.456f) *(float*)p.out = 0.f; return; }  // no math, no stores
+#endif
   if constexpr (STORE == VDN_ST_PLAIN || STORE == VDN_ST_CONVT) {
     if (p.bias) a += *(const f32x4*)(p.bias + n);
     if (p.rowadd) a += p.rowadd[m];
     if (p.act == VDN_ACT_GELU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = gelu_fast(a[e]);
+      a = gelu4(a);
     } else if (p.act == VDN_ACT_RELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
@@ -67,6 +69,9 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     } else {
       o = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc + n;
     }
+#if defined(VDN_ABLATE) && (VDN_ABLATE & 16)
+    if (p.M > 0) { if (a[0] + a[1] + a[2] + a[3] == 123.456f) *(float*)p.out = 0.f; return; }  // math, no stores
+#endif
     if (p.out_dt == VDN_F32) {
       *(f32x4*)((float*)p.out + o) = a;
     } else if (p.out_lo) {
@@ -74,6 +79,9 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
 #pragma unroll
       for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
       *(typename H::V4*)((T*)p.out + o) = h;
+#if defined(VDN_ABLATE) && (VDN_ABLATE & 32)
+      if (l[0] + l[1] == (T)123.f)  // hi plane only
+#endif
       *(typename H::V4*)((T*)p.out_lo + o) = l;
     } else {
       typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
@@ -83,8 +91,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     // packed columns: 16-wide blocks alternate [h | gate]
     if ((n & 16) || n + 16 >= p.N) return;
     if (p.bias) { a += *(const f32x4*)(p.bias + n); b += *(const f32x4*)(p.bias + n + 16); }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = a[e] * gelu_fast(b[e]);
+    a = a * gelu4(b);
     const size_t o = (size_t)m * p.ldc + ((n >> 5) << 4) + (n & 15);
     if (p.out_dt == VDN_F32) {
       *(f32x4*)((float*)p.out + o) = a;
@@ -698,20 +705,31 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   }
 
   // one K step on stage `cur`; STAGED: the next stage's DMA is issued inside the step
+#ifndef VDN_ABLATE
+#define VDN_ABLATE 0  // tools/gemm_ablate.sh only: 1 = no DMA in the loop, 2 = no LDS reads in the loop, 4 = no MFMA
+#endif
+#if VDN_ABLATE & 2
+  V8 bh[TNW], bl[TNW], ah[2][HALF], al[2][HALF];
+#endif
   auto step = [&](int kt, auto staged) {
     constexpr bool STAGED = decltype(staged)::value;
     const int cur = kt & 1;
-    if constexpr (STAGED) {
+    if constexpr (STAGED && !(VDN_ABLATE & 1)) {
       if constexpr (CONV) stage(cur ^ 1, kt + 1); else stage_plain(cur ^ 1);
     }
     const char* s0 = smem + cur * STAGE;
+#if VDN_ABLATE & 2
+    if (kt == 0) {
+#else
     V8 bh[TNW], bl[TNW];
+    V8 ah[2][HALF], al[2][HALF];
+    {
+#endif
 #pragma unroll
     for (int t = 0; t < TNW; ++t) {
       bh[t] = *(const V8*)(s0 + b_off[t]);
       bl[t] = *(const V8*)(s0 + W_TILE + b_off[t]);
     }
-    V8 ah[2][HALF], al[2][HALF];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -720,6 +738,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
         al[hf][t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
         if constexpr (RELU_A) { ah[hf][t] = relu8(ah[hf][t]); al[hf][t] = relu8(al[hf][t]); }
       }
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -727,9 +746,13 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
           f32x4 c = acc[hf * HALF + i][j];
+#if VDN_ABLATE & 4
+          c[0] += (float)bh[j][0] * (float)al[hf][i][0] + (float)bl[j][1] * (float)ah[hf][i][1];
+#else
           c = H::mfma16(bh[j], al[hf][i], c);
           c = H::mfma16(bl[j], ah[hf][i], c);
           c = H::mfma16(bh[j], ah[hf][i], c);
+#endif
           acc[hf * HALF + i][j] = c;
         }
     stage_barrier();
