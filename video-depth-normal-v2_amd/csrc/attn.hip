@@ -15,10 +15,15 @@
 //
 // temporal_attn_kernel — <= 32 frames per (pixel, head): one wave per sequence, fragments loaded
 //   straight from global memory (no LDS), same accumulator-as-operand chaining.
+#define VDN_ATTN_EXPERIMENT 1
 #include "common.hpp"
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
+__device__ __forceinline__ bool lane_hi() { return (threadIdx.x & 32) != 0; }
 __device__ __forceinline__ int perm23(int i) {  // swap bits 2 and 3
   return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
@@ -27,12 +32,28 @@ __device__ __forceinline__ int acc_key(int reg, int h) {
   return (reg & 3) + 4 * ((reg >> 2) & 1) + 8 * h + 16 * (reg >> 3);
 }
 
+// value held by the same row's lane in the other 32-lane half (v_permlane32_swap: VALU, no LDS round trip)
+__device__ __forceinline__ float xhalf(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (lane_hi() ? r[0] : r[1]));
+}
+
+template <class F, int... J>
+__device__ __forceinline__ void for_each_slot_impl(F& f, std::integer_sequence<int, J...>) {
+  (f(std::integral_constant<int, J>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void for_each_slot(F& f) {
+  for_each_slot_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 #define GLDS16(src, dst)                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 template <int DT, bool SPLIT>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>::T* __restrict__ Q,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_kernel(const typename Half<DT>::T* __restrict__ Q,
                                                          const typename Half<DT>::T* __restrict__ K,
                                                          const typename Half<DT>::T* __restrict__ Vt,
                                                          typename Half<DT>::T* __restrict__ out,
@@ -40,7 +61,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
                                                          const typename Half<DT>::T* __restrict__ Kl,
                                                          const typename Half<DT>::T* __restrict__ Vtl,
                                                          typename Half<DT>::T* __restrict__ outl, int H, int nq,
-                                                         int nq_pad, int nk, int nk_pad, float scale_log2) {
+                                                         int nq_pad, int nk, int nk_pad, float scale_log2, int stagger_cycles) {
   using HT = Half<DT>;
   using T = typename HT::T;
   using V8 = typename HT::V8;
@@ -76,120 +97,231 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const typename Half<DT>
   const int lr = lane >> 3;
   const size_t kbase = (size_t)bh * nk_pad * 64;
   const size_t vbase = (size_t)bh * 64 * nk_pad;
-  auto stage = [&](int buf, int t) {
+  auto stage_k = [&](int buf, int t) {
     char* sK = smem + buf * NT * TILE;
-    char* sV = sK + TILE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 4 * i;
       const int row = pc * 8 + lr;
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       const size_t ko = kbase + (size_t)(t * 64 + row) * 64 + c * 8;
-      const size_t vo = vbase + (size_t)row * nk_pad + t * 64 + c * 8;
       GLDS16(K + ko, sK + pc * 1024);
+      if constexpr (SPLIT) GLDS16(Kl + ko, sK + 2 * TILE + pc * 1024);
+    }
+  };
+  auto stage_v = [&](int buf, int t) {
+    char* sV = smem + buf * NT * TILE + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 4 * i;
+      const int row = pc * 8 + lr;
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      const size_t vo = vbase + (size_t)row * nk_pad + t * 64 + c * 8;
       GLDS16(Vt + vo, sV + pc * 1024);
-      if constexpr (SPLIT) {
-        GLDS16(Kl + ko, sK + 2 * TILE + pc * 1024);
-        GLDS16(Vtl + vo, sV + 2 * TILE + pc * 1024);
-      }
+      if constexpr (SPLIT) GLDS16(Vtl + vo, sV + 2 * TILE + pc * 1024);
     }
   };
 
-  // ---- fragment read offsets
-  int k_off[2][4], v_off[2][4];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int row = kb * 32 + perm23(r);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) k_off[kb][ks] = row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
-  }
-#pragma unroll
-  for (int db = 0; db < 2; ++db) {
-    const int row = db * 32 + r;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v_off[db][c] = row * 128 + (((2 * c + h) ^ ((row >> 1) & 7)) << 4);
-  }
+  // ---- fragment read offsets. Row r (+32 kb) of a tile, 16-byte chunk (2 ks + h) ^ swz(row): the kb / db
+  // term is a compile-time immediate and the ks / c term an XOR with (ks << 5), so ONE register per operand
+  // is kept (not 8) and the address of each fragment pair costs one v_xor (the loop is register-bound).
+  const int k_base = perm23(r) * 128 + ((h ^ ((perm23(r) >> 1) & 7)) << 4);
+  const int v_base = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
+  auto k_addr = [&](int kb, int ks) { return kb * 4096 + (k_base ^ (ks << 5)); };
+  auto v_addr = [&](int db, int c) { return db * 4096 + (v_base ^ (c << 5)); };
 
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f, l_run = 0.f;  // running max in the RAW score domain; the scale is folded into the exp2 argument
 
-  const int nt = (nk + 63) >> 6;
-  stage(0, 0);
-  stage_barrier();
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) stage(cur ^ 1, t + 1);
-    const char* sK = smem + cur * NT * TILE;
-    const char* sV = sK + TILE;
-
-    f32x16 s[2];
+  // S^T of one 64-key tile from K buffer `buf`
+  auto qk = [&](int buf, f32x16 (&sc)[2]) {
+    const char* sK = smem + buf * NT * TILE;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const V8 a = *(const V8*)(sK + k_off[kb][ks]);
-        s[kb] = HT::mfma32(a, qf[ks], s[kb]);
+        const V8 a = *(const V8*)(sK + k_addr(kb, ks));
+        sc[kb] = HT::mfma32(a, qf[ks], sc[kb]);
         if constexpr (SPLIT) {
-          const V8 al = *(const V8*)(sK + 2 * TILE + k_off[kb][ks]);
-          s[kb] = HT::mfma32(a, ql[ks], s[kb]);
-          s[kb] = HT::mfma32(al, qf[ks], s[kb]);
+          const V8 al = *(const V8*)(sK + 2 * TILE + k_addr(kb, ks));
+          sc[kb] = HT::mfma32(a, ql[ks], sc[kb]);
+          sc[kb] = HT::mfma32(al, qf[ks], sc[kb]);
         }
       }
     }
-    // scale into the log2 domain, mask the ragged last tile
-    const bool tail = (t + 1) * 64 > nk;
-    float mx = -1e30f;
+  };
+  // O^T += V^T P^T of one tile from V buffer `buf`
+  auto pv = [&](int buf, const V8 (&pf)[2][2], const V8 (&pl)[2][2]) {
+    const char* sV = smem + buf * NT * TILE + TILE;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int c = 0; c < 4; ++c)  // c outer: a P fragment is dead after its 6 MFMAs (registers for the next tile's P)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float v = s[kb][i] * scale_log2;
-        if (tail) v = (t * 64 + kb * 32 + acc_key(i, h) < nk) ? v : -INFINITY;
-        s[kb][i] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float ls = 0.f;
-    V8 pf[2][2], pl[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb][i] - m_new);
-        ls += pv;
-        if constexpr (SPLIT) {
-          T a, b;
-          split_rtz(pv, a, b);
-          pf[kb][i >> 3][i & 7] = a;
-          pl[kb][i >> 3][i & 7] = b;
-        } else {
-          pf[kb][i >> 3][i & 7] = (T)pv;
-        }
-      }
-    l_run = l_run * alpha + ls;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const V8 a = *(const V8*)(sV + v_off[db][c]);
+      for (int db = 0; db < 2; ++db) {
+        const V8 a = *(const V8*)(sV + v_addr(db, c));
         o[db] = HT::mfma32(a, pf[c >> 1][c & 1], o[db]);
         if constexpr (SPLIT) {
-          const V8 al = *(const V8*)(sV + 2 * TILE + v_off[db][c]);
+          const V8 al = *(const V8*)(sV + 2 * TILE + v_addr(db, c));
           o[db] = HT::mfma32(a, pl[c >> 1][c & 1], o[db]);
           o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
         }
       }
+  };
+
+  // Three-stage software pipeline, all in ONE basic block per iteration so the scheduler can slot the
+  // softmax VALU work into the MFMA gaps of the SAME wave (an in-order wave only overlaps the two pipes
+  // when they alternate in program order; PMC before: VALU busy 46 % + MFMA busy 53 % = 99 %, i.e. serial):
+  //     iteration t:   S(t+1) = K_{t+1} Q^T   ||   P(t) = softmax-numerator(S(t))   ||   O += V_{t-1} P(t-1)
+  // LDS ring (2 buffers each): iteration t reads K_{t+1} and V_{t-1}; its DMA fills K_{t+2} (buffer of K_t,
+  // consumed in iteration t-1) and V_t (buffer of V_{t-2}, consumed in iteration t-1).
+  // Lazy rescale: the reference point m_run moves only when some row's tile maximum exceeds it by more than
+  // 2^LAZY (P stays <= 2^LAZY: exact in fp32 / split fp16; the 1/l normalisation makes the result
+  // independent of the reference), so in steady state the O accumulators are never touched by the VALU.
+  constexpr float LAZY = 6.0f;
+  const int nt = (nk + 63) >> 6;
+  f32x16 s[2];
+  V8 pf[2][2], pl[2][2];
+  auto iter = [&](int t, auto has_prev_c, auto has_next_c) {
+    constexpr bool HAS_PREV = decltype(has_prev_c)::value, HAS_NEXT = decltype(has_next_c)::value;
+    const int cur = t & 1;
+    stage_v(cur, t);
+    if constexpr (HAS_NEXT) {
+      if (t + 2 < nt) stage_k(cur, t + 2);
+    }
+    if constexpr (!HAS_NEXT) {  // only the last tile can be ragged
+      if ((t + 1) * 64 > nk) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (t * 64 + kb * 32 + acc_key(i, h) >= nk) s[kb][i] = -INFINITY;
+      }
+    }
+    const char* sKn = smem + (cur ^ 1) * NT * TILE;         // K_{t+1}
+    const char* sVp = smem + (cur ^ 1) * NT * TILE + TILE;  // V_{t-1}
+
+    // ---- hand-placed stream: 48 slots = 16 MFMA triples (8 of PV(t-1), c outer; then 8 of QK(t+1)), each
+    // slot = one small piece of softmax(t) + one MFMA, fenced by sched_barrier so the order survives the
+    // scheduler (its own choice is all MFMAs first, then all VALU: no overlap inside the in-order wave;
+    // sched_group_barrier pipelines were not honoured on this block). A 32x32x16 MFMA keeps the matrix pipe
+    // 32 cycles and the issue port 8, so <= 24 cycles of VALU issue per slot are hidden.
+    // S and P are updated IN PLACE (the loop is register-bound: O 32 + S 32 + Q 32 + P 32 + fragments):
+    //   P fragment f is read by PV(t-1) in slots 6f..6f+5 and rewritten by softmax(t) in slots >= 7+8f;
+    //   S[0] is last read in slot 20 and overwritten by QK(t+1) from slot 24, S[1] read in 36 (softmax piece
+    //   first in the slot), overwritten from slot 36's MFMA on.
+    V8 fa[2], fl[2];
+    auto frag = [&](auto jc, V8& a, V8& al) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j < 8) {
+        if constexpr (HAS_PREV) {
+          a = *(const V8*)(sVp + v_addr(j & 1, j >> 1));
+          if constexpr (SPLIT) al = *(const V8*)(sVp + 2 * TILE + v_addr(j & 1, j >> 1));
+        }
+      } else if constexpr (HAS_NEXT) {
+        a = *(const V8*)(sKn + k_addr((j - 8) >> 2, (j - 8) & 3));
+        if constexpr (SPLIT) al = *(const V8*)(sKn + 2 * TILE + k_addr((j - 8) >> 2, (j - 8) & 3));
+      }
+    };
+    auto mma = [&](auto jc, auto qc, const V8& a, const V8& al) {
+      constexpr int j = decltype(jc)::value, q = decltype(qc)::value;
+      if constexpr (!SPLIT && q > 0) return;
+      if constexpr (j < 8) {
+        if constexpr (HAS_PREV) {
+          constexpr int c = j >> 1, db = j & 1;
+          if constexpr (q == 0) o[db] = HT::mfma32(a, pf[c >> 1][c & 1], o[db]);
+          if constexpr (q == 1) o[db] = HT::mfma32(a, pl[c >> 1][c & 1], o[db]);
+          if constexpr (q == 2) o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
+        }
+      } else if constexpr (HAS_NEXT) {
+        constexpr int kb = (j - 8) >> 2, ks = (j - 8) & 3;
+        if constexpr (ks == 0 && q == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) z[i] = 0.f;
+          s[kb] = HT::mfma32(a, qf[ks], z);
+        } else {
+          if constexpr (q == 0) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
+          if constexpr (q == 1) s[kb] = HT::mfma32(a, ql[ks], s[kb]);
+          if constexpr (q == 2) s[kb] = HT::mfma32(al, qf[ks], s[kb]);
+        }
+      }
+    };
+    float mx = -1e30f, alpha = 1.f, mb = 0.f, ls = 0.f, px0 = 0.f, px1 = 0.f;
+    bool bump = false;
+    auto vstep = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < 4) {  // tile maximum, 8 scores per slot
+        constexpr int kb = k >> 1, i = (k & 1) * 8;
+        mx = fmaxf(fmaxf(mx, s[kb][i]), s[kb][i + 1]);
+        mx = fmaxf(fmaxf(mx, s[kb][i + 2]), s[kb][i + 3]);
+        mx = fmaxf(fmaxf(mx, s[kb][i + 4]), s[kb][i + 5]);
+        mx = fmaxf(fmaxf(mx, s[kb][i + 6]), s[kb][i + 7]);
+      } else if constexpr (k == 4) {
+        mx = fmaxf(mx, xhalf(mx));
+      } else if constexpr (k == 5) {
+        bump = __builtin_amdgcn_ballot_w64((mx - m_run) * scale_log2 > LAZY) != 0;  // wave-uniform
+        const float m_new = bump ? fmaxf(m_run, mx) : m_run;
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);  // == 1 when not bumped
+        m_run = m_new;
+        mb = -m_new * scale_log2;
+      } else if constexpr (k < 38) {
+        constexpr int pi = (k - 6) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
+        if constexpr (((k - 6) & 1) == 0) {
+          px0 = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2, mb));
+          px1 = __builtin_amdgcn_exp2f(fmaf(s[kb][i + 1], scale_log2, mb));
+        } else {
+          ls += px0 + px1;
+          if constexpr (SPLIT) {
+            T a0, a1, b0, b1;
+            split2_rtz(px0, px1, a0, a1, b0, b1);
+            pf[kb][i >> 3][i & 7] = a0; pf[kb][i >> 3][(i & 7) + 1] = a1;
+            pl[kb][i >> 3][i & 7] = b0; pl[kb][i >> 3][(i & 7) + 1] = b1;
+          } else {
+            pf[kb][i >> 3][i & 7] = (T)px0; pf[kb][i >> 3][(i & 7) + 1] = (T)px1;
+          }
+        }
+      } else if constexpr (k == 38) {
+        l_run = l_run * alpha + ls;
+      }
+    };
+    auto slot = [&](auto jc) {
+      constexpr int j = decltype(jc)::value, tj = j / 3, q = j % 3;
+      if constexpr (q == 0 && tj + 1 < 16) frag(std::integral_constant<int, tj + 1>{}, fa[(tj + 1) & 1], fl[(tj + 1) & 1]);
+      vstep(jc);
+      mma(std::integral_constant<int, tj>{}, std::integral_constant<int, q>{}, fa[tj & 1], fl[tj & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    frag(std::integral_constant<int, 0>{}, fa[0], fl[0]);
+    for_each_slot<48>(slot);
+
+    // P(t) is only consumed by the next iteration's MFMAs: keep LLVM from sinking its computation there.
+    asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1]));
+    if constexpr (SPLIT) asm volatile("" : "+v"(pl[0][0]), "+v"(pl[0][1]), "+v"(pl[1][0]), "+v"(pl[1][1]));
+    if (bump) {  // O is in the old reference (it just received tile t-1): move it to the new one
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    }
     stage_barrier();
+  };
+
+  stage_k(0, 0);
+  if (nt > 1) stage_k(1, 1);
+  stage_barrier();
+  qk(0, s);
+  stage_barrier();  // every wave has read K_0 before iteration 0 lets K_2 overwrite it
+  constexpr std::true_type Y{};
+  constexpr std::false_type N{};
+  if (nt == 1) {
+    iter(0, N, N);
+  } else {
+    iter(0, N, Y);
+    for (int t = 1; t + 1 < nt; ++t) iter(t, Y, Y);
+    iter(nt - 1, Y, N);
   }
+  pv((nt - 1) & 1, pf, pl);
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
@@ -356,13 +488,18 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
                  void* outl, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
   using T = typename Half<DT>::T;
   const dim3 grid(((nq + 127) / 128) * B * H);
+  int extra = 0, stag = 0;
+#ifdef VDN_ATTN_EXPERIMENT
+  if (const char* e = getenv("VDN_ATTN_LDS")) extra = atoi(e);
+  if (const char* e = getenv("VDN_ATTN_STAGGER")) stag = atoi(e);
+#endif
   if (Ql)
-    hipLaunchKernelGGL((flash_attn_kernel<DT, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
+    hipLaunchKernelGGL((flash_attn_kernel<DT, true>), grid, dim3(256), 65536 + extra, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2, stag);
   else
-    hipLaunchKernelGGL((flash_attn_kernel<DT, false>), grid, dim3(256), 32768, s, (const T*)Q, (const T*)K, (const T*)Vt,
+    hipLaunchKernelGGL((flash_attn_kernel<DT, false>), grid, dim3(256), 32768 + extra, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, H, nq, nq_pad, nk,
-                       nk_pad, sl2);
+                       nk_pad, sl2, stag);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
