@@ -31,16 +31,92 @@ constexpr int BK = 64;
 // then one 8- or 16-byte store per plane in the layout the consumer reads (plain rows, per-head
 // Q/K/V^T with RoPE, pixel-shuffle, GEGLU). `b` is the group 16 columns to the right (the GEGLU gate /
 // the RoPE imaginary parts, which the weight packing put there).
+// `bias_a` / `bias_b` / `gam` are the bias of this group, the bias of the group 16 columns to the right and the
+// LayerScale factor, loaded ONCE per wave before the first store (0 / 0 / 1 when the operand is absent): a
+// load inside the store loop waits on vmcnt, which on gfx9 also counts the stores issued before it, so
+// every group paid a full store round trip (measured: 10 us of "math" per tile round that was latency).
+// internal store codes (never in a descriptor): specialised epilogues, see emit4 / epi_flavour
+constexpr int VDN_STX_FC1 = 100, VDN_STX_RES = 101, VDN_STX_HEADS = 102;
+
+// Which straight-line flavour (if any) computes exactly what descriptor `d` asks for.
+inline int epi_flavour(const vdn_gemm_desc& d) {
+  const bool half_out = d.out_dt != VDN_F32;
+  if (d.store == VDN_ST_PLAIN && d.bias && d.act == VDN_ACT_GELU && !d.rowadd && !d.gamma && !d.tab && !d.res1 && !d.res2 &&
+      half_out && d.out_lo && d.row_group <= 0)
+    return VDN_STX_FC1;
+  if (d.store == VDN_ST_PLAIN && d.act == VDN_ACT_NONE && !d.rowadd && !d.tab && d.res1 && d.res1_dt == VDN_F32 && !d.res1_lo &&
+      !d.res2 && d.out_dt == VDN_F32 && d.row_group <= 0)
+    return VDN_STX_RES;
+  if (d.store == VDN_ST_HEADS && !d.rope[0] && !d.rope[1] && !d.rope[2] && d.nsplit >= 1) {
+    for (int i = 0; i < d.nsplit; ++i)
+      if (!d.dst[i] || !d.dst_lo[i]) return d.store;
+    return VDN_STX_HEADS;
+  }
+  return d.store;
+}
+
 template <int DT, int STORE>
-__device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x4 a, f32x4 b) {
+__device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x4 a, f32x4 b, f32x4 bias_a, f32x4 bias_b,
+                                      f32x4 gam) {
   using H = Half<DT>;
   using T = typename H::T;
   if (m >= p.M || n >= p.N) return;
+  // ---- straight-line flavours of the hot epilogues (chosen on the host by epi_flavour()): the generic code
+  // below tests ~40 wave-uniform descriptor fields per group, and with 32 groups per lane and only two waves
+  // per SIMD those scalar branches were 12 us of every 31 us tile round at K = 32 (tools/gemm_ablate.sh).
+  if constexpr (STORE == VDN_STX_FC1) {  // bias + GELU -> split half planes, plain rows
+    a = gelu4(a + bias_a);
+    const size_t o = (size_t)m * p.ldc + n;
+    typename H::V4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      T h0, h1, l0, l1;
+      split2_rtz(a[e], a[e + 1], h0, h1, l0, l1);
+      h[e] = h0; h[e + 1] = h1; l[e] = l0; l[e + 1] = l1;
+    }
+    *(typename H::V4*)((T*)p.out + o) = h;
+    *(typename H::V4*)((T*)p.out_lo + o) = l;
+    return;
+  } else if constexpr (STORE == VDN_STX_RES) {  // (acc + bias) * gamma + f32 residual -> f32 rows
+    a = (a + bias_a) * gam + *(const f32x4*)((const float*)p.res1 + (size_t)m * p.ldr1 + n);
+    *(f32x4*)((float*)p.out + (size_t)m * p.ldc + n) = a;
+    return;
+  } else if constexpr (STORE == VDN_STX_HEADS) {  // bias -> per-head Q / K rows or V^T columns, split planes, no RoPE
+    const int hc = p.heads * 64;
+    const int bt = m / p.tokens, tl = m - bt * p.tokens;
+    const int tk = tl + p.tok_off;
+    const int split = n / hc;
+    const int head = (n - split * hc) >> 6, e0 = n & 63;
+    const size_t hb = (size_t)bt * p.heads + head;
+    T* dst = (T*)p.dst[split];
+    T* dlo = (T*)p.dst_lo[split];
+    a += bias_a;
+    typename H::V4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      T h0, h1, l0, l1;
+      split2_rtz(a[e], a[e + 1], h0, h1, l0, l1);
+      h[e] = h0; h[e + 1] = h1; l[e] = l0; l[e + 1] = l1;
+    }
+    if (p.transposed[split]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const size_t o = (hb * 64 + e0 + e) * p.tpad + tk;
+        dst[o] = h[e];
+        dlo[o] = l[e];
+      }
+    } else {
+      const size_t o = (hb * p.tpad + tk) * 64 + e0;
+      *(typename H::V4*)(dst + o) = h;
+      *(typename H::V4*)(dlo + o) = l;
+    }
+    return;
+  }
 #if defined(VDN_ABLATE) && (VDN_ABLATE & 8)
   if (p.M > 0) { if (a[0] + a[1] + a[2] + a[3] == 123.456f) *(float*)p.out = 0.f; return; }  // no math, no stores
 #endif
   if constexpr (STORE == VDN_ST_PLAIN || STORE == VDN_ST_CONVT) {
-    if (p.bias) a += *(const f32x4*)(p.bias + n);
+    a += bias_a;
     if (p.rowadd) a += p.rowadd[m];
     if (p.act == VDN_ACT_GELU) {
       a = gelu4(a);
@@ -48,7 +124,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
     }
-    if (p.gamma) a *= *(const f32x4*)(p.gamma + n);
+    a *= gam;
     if (p.tab) a += *(const f32x4*)(p.tab + (size_t)(m % p.tab_mod + p.tab_off) * p.N + n);
     if (p.res1) {
       a += load4_as_float(p.res1, p.res1_dt, (size_t)m * p.ldr1 + n);
@@ -90,7 +166,8 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
   } else if constexpr (STORE == VDN_ST_GEGLU) {
     // packed columns: 16-wide blocks alternate [h | gate]
     if ((n & 16) || n + 16 >= p.N) return;
-    if (p.bias) { a += *(const f32x4*)(p.bias + n); b += *(const f32x4*)(p.bias + n + 16); }
+    a += bias_a;
+    b += bias_b;
     a = a * gelu4(b);
     const size_t o = (size_t)m * p.ldc + ((n >> 5) << 4) + (n & 15);
     if (p.out_dt == VDN_F32) {
@@ -114,10 +191,10 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     const size_t hb = (size_t)bt * p.heads + head;
     T* dst = (T*)p.dst[split];
     T* dlo = (T*)p.dst_lo[split];
-    if (p.bias) a += *(const f32x4*)(p.bias + n);
+    a += bias_a;
     if (p.rope[split]) {
       if (e0 & 16) return;  // imaginary group: consumed together with its real partner
-      if (p.bias) b += *(const f32x4*)(p.bias + n + 16);
+      b += bias_b;
       const int pi = ((e0 >> 5) << 4) + (e0 & 15);  // first of 4 consecutive pair indices
       const float* cs = p.rope_cs + (size_t)(tl % p.rope_mod) * 64 + 2 * pi;
       float o8[8];
@@ -165,11 +242,19 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
 template <int DT, int TM, int TN, int STORE>
 __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
+  f32x4 bias4[TN], gam4[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 16 + fq * 4;
+    bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gam4[j] = (p.gamma && n < p.N) ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      emit4<DT, STORE>(p, mw + i * 16 + fr, nw + j * 16 + fq * 4, acc[i][j], acc[i][j + 1 < TN ? j + 1 : j]);
+      emit4<DT, STORE>(p, mw + i * 16 + fr, nw + j * 16 + fq * 4, acc[i][j], acc[i][j + 1 < TN ? j + 1 : j], bias4[j],
+                       bias4[j + 1 < TN ? j + 1 : j], gam4[j]);
 }
 
 // Epilogue through a wave-private LDS transpose (8-wave kernels, wave tile 16 TM x 64): each 16-row slab of
@@ -193,7 +278,11 @@ __device__ __forceinline__ void epilogue_wave_lds(f32x4 (&acc)[TM][4], const vdn
       const f32x4 a = *(const f32x4*)(wl + row * LDW + cc);
       f32x4 b = a;
       if constexpr (STORE == VDN_ST_GEGLU || STORE == VDN_ST_HEADS) b = *(const f32x4*)(wl + row * LDW + ((cc + 16) & 63));
-      emit4<DT, STORE>(p, mw + i * 16 + row, nw + cc, a, b);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, o4 = {1.f, 1.f, 1.f, 1.f};
+      const bool okc = nw + cc < p.N;
+      emit4<DT, STORE>(p, mw + i * 16 + row, nw + cc, a, b, (p.bias && okc) ? *(const f32x4*)(p.bias + nw + cc) : z4,
+                       (p.bias && nw + cc + 16 < p.N) ? *(const f32x4*)(p.bias + nw + cc + 16) : z4,
+                       (p.gamma && okc) ? *(const f32x4*)(p.gamma + nw + cc) : o4);
     }
   }
 }
@@ -695,6 +784,13 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
     for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if VDN_ABLATE & 64
+  f32x16 acc32[TMW];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+#endif
   // plain rows advance by pointer increments with no K-tail select: stop at K (a multiple of 32 on this
   // path), NOT at the padded weight stride — reading A columns K..ldb would run into the next row and,
   // on the last row, past the buffer (0 x NaN = NaN even though the padded weights are zero).
@@ -739,6 +835,23 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
         if constexpr (RELU_A) { ah[hf][t] = relu8(ah[hf][t]); al[hf][t] = relu8(al[hf][t]); }
       }
     }
+#if VDN_ABLATE & 64
+    // timing experiment only (results meaningless): the same fragments through half as many 32x32x16 MFMAs
+    // (32 pipe cycles, 8 issue cycles each) instead of 16x16x32 (16 pipe / 8 issue)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < HALF; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; j += 2) {
+          f32x16& c = acc32[((hf * HALF + i) >> 1) * 2 + (j >> 1)];
+          c = H::mfma32(bh[j], al[hf][i], c);
+          c = H::mfma32(bl[j + 1], ah[hf][i], c);
+          c = H::mfma32(bh[j + 1], ah[hf][i], c);
+        }
+    stage_barrier();
+    return;
+#endif
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -831,7 +944,265 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 
   // (epilogue_wave_lds — row-contiguous stores through a wave-private LDS transpose — measured 8 % SLOWER on
   //  the whole forward in a same-box A/B although faster on isolated plain-store GEMMs; kept for reference)
+#if VDN_ABLATE & 64
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] += acc32[(i >> 1) * 2 + (j >> 1)][(i & 1) * 8 + (j & 1) * 4 + e];
+#endif
   epilogue_regs<DT, TMW, TNW, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_x3_p8_kernel: 256 x 256 x 32 tile, 8 waves, split operands, ping-pong phases.
+//
+// The BM x 256 kernel above has every wave do the same thing at the same time (issue DMA, read fragments,
+// 96 MFMAs, barrier): the matrix pipe idles while all waves issue / wait, and the per-CU L2->LDS feed idles
+// while all waves multiply (tools/gemm_ablate.sh: MFMA-only 1.27 us + DMA-only 1.16 us -> 1.89 us per K step).
+// Here the two wave groups (waves 0-3 = A rows 0..127, waves 4-7 = A rows 128..255; wave w and w+4 share
+// a SIMD) run ONE BARRIER APART: between two consecutive barriers one group multiplies a 64 x 32 quadrant
+// of its 128 x 64 output (24 MFMAs = 384 pipe cycles) while the other reads its next fragments from LDS
+// and issues its share of the next K tile's DMA. Per K tile (4 phases, quadrants (0,0) (0,1) (1,1) (1,0)):
+//     phase    LDS fragment reads          DMA unit issued (next K tile, 16 KiB = 2 pieces per wave)
+//       1      A sub-half 0, W sub-half 0   A rows {0-63, 128-191}      (read in phase 1 of the next tile)
+//       2      W sub-half 1                 W rows {32 j .. 32 j + 15 ...} sub-half 0  (phase 1 and 4)
+//       3      A sub-half 1                 W sub-half 1                               (phase 2)
+//       4      W sub-half 0                 A rows {64-127, 192-255}                   (phase 3)
+// Ordering (MI355X_MICROARCH.md 'Two waves per SIMD' item 7, guide '256^2 8-phase template'):
+//   RAW: a unit issued in phase p is read no earlier than phase p+3: every wave waits vmcnt(4) (all but its
+//        two newest units) before the first barrier of phase p+2, and because the groups are one barrier
+//        apart one more barrier has to pass before the other group's pieces are covered.
+//   WAR: a unit's LDS region is last read >= 2 phases before it is re-issued (W sub-half 0: read in phase 4,
+//        re-issued in phase 2 of the next tile; the reads are retired by the lgkmcnt(0) after that phase's
+//        first barrier, two barriers before the earliest re-issue by either group).
+//   The last K tile issues nothing, so its waits count down 2, 0 instead of 4.
+template <int DT, int AMODE, int STORE, int BM>
+__global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) {
+  using H = Half<DT>;
+  using V8 = typename H::V8;
+  using T = typename H::T;
+  static_assert(BM == 256 || BM == 192, "A sub-halves of 64 or 48 rows");
+  constexpr int BN = 256, BK3 = 32;
+  constexpr int A_TILE = BM * 64, W_TILE = BN * 64;  // bytes per operand plane and stage
+  constexpr int STAGE = 2 * A_TILE + 2 * W_TILE;     // A_hi | A_lo | W_hi | W_lo
+  constexpr int TQ = BM / 64;                        // 16-row fragments per A sub-half (per wave and phase)
+  constexpr bool CONV = (AMODE == 1 || AMODE == 2);
+  constexpr bool RELU_A = (AMODE == 2 || AMODE == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm_i, tn_i;
+  {
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int g = tile / per_group, r = tile - g * per_group;
+    const int gm = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tn_i = r / gm;
+    tm_i = g * GM + (r - tn_i * gm);
+  }
+  const int m0 = tm_i * BM, n0 = tn_i * BN;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- DMA duty of this wave: one 16-row piece (x 2 planes) of each of the four units
+  const int lr = lane >> 2;
+  const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+  // A unit = sub-half `sh` of both groups = 2 TQ pieces x 2 planes. BM 256: 16 piece-planes, wave w takes both
+  // planes of piece-list entry w. BM 192: 12 piece-planes: waves 0-3 both planes of entries 0-3, waves 4-7
+  // ONE plane of entries 4, 4, 5, 5 (their counted waits differ, see VDN_PHASE).
+  const int a_li = (BM == 256 || wave < 4) ? wave : 4 + ((wave - 4) >> 1);
+  const bool a_both = BM == 256 || wave < 4;
+  const int a_plane = a_both ? 0 : (wave & 1);
+  const int pa[2] = {(a_li / TQ) * 2 * TQ + a_li % TQ, (a_li / TQ) * 2 * TQ + TQ + a_li % TQ};
+  const int pw[2] = {4 * (wave >> 1) + (wave & 1), 4 * (wave >> 1) + (wave & 1) + 2};  // W pieces of sub-half 0 / 1
+  const T* A = (const T*)p.A;
+  const T* a_row[2];
+  int a_iy[2], a_ix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + pa[i] * 16 + lr;
+    m = m < p.M ? m : p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.cOH * p.cOW;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+      a_row[i] = A + (size_t)b * p.cH * p.cW * p.cC;
+      a_iy[i] = oy * p.cstride - 1;
+      a_ix[i] = ox * p.cstride - 1;
+    } else {
+      a_row[i] = A + (size_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  const char* zeros = (const char*)p.zeros;
+  const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
+  const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
+  const char* ap[2];
+  const char* wp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int n = n0 + pw[i] * 16 + lr;
+    n = n < p.N ? n : p.N - 1;
+    wp[i] = (const char*)((const T*)p.W + (size_t)n * p.ldb + chunk * 8);
+    ap[i] = (const char*)(a_row[i] + chunk * 8);
+  }
+#define VDN_GLDS(src, dst)                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+  // unit u of K tile kt into stage `buf`: 0 = A sub-half 0, 1 = W sub-half 0, 2 = W sub-half 1, 3 = A sub-half 1
+  auto issue = [&](auto uc, int buf, int kt) {
+    constexpr int u = decltype(uc)::value;
+    char* s0 = smem + buf * STAGE;
+    if constexpr (u == 0 || u == 3) {
+      constexpr int i = u == 0 ? 0 : 1;
+      char* dst = s0 + pa[i] * 1024;
+      if constexpr (CONV) {
+        int tap, ci;
+        const int k = kt * BK3 + chunk * 8;
+        if (p.conv_korder) {
+          const int half = kt & 1, t2 = kt >> 1;
+          const int c64 = t2 / 9;
+          tap = t2 - c64 * 9;
+          ci = c64 * 64 + half * 32 + chunk * 8;
+          if (ci >= p.cC) tap = 9;
+        } else {
+          tap = (int)(((float)(k >> 3) + 0.5f) * (1.0f / (float)(p.cC >> 3)));
+          ci = k - tap * p.cC;
+        }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+        const char* src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+        if (a_both) {
+          VDN_GLDS(ok ? src : zeros, dst);
+          VDN_GLDS(ok ? src + a_delta : zeros, dst + A_TILE);
+        } else {
+          VDN_GLDS(ok ? src + (a_plane ? a_delta : 0) : zeros, dst + a_plane * A_TILE);
+        }
+      } else {
+        if (a_both) {
+          VDN_GLDS(ap[i], dst);
+          VDN_GLDS(ap[i] + a_delta, dst + A_TILE);
+        } else {
+          VDN_GLDS(ap[i] + (a_plane ? a_delta : 0), dst + a_plane * A_TILE);
+        }
+        ap[i] += 64;
+      }
+    } else {
+      constexpr int i = u == 1 ? 0 : 1;
+      char* dst = s0 + 2 * A_TILE + pw[i] * 1024;
+      VDN_GLDS(wp[i], dst);
+      VDN_GLDS(wp[i] + w_delta, dst + W_TILE);
+      wp[i] += 64;
+    }
+  };
+#undef VDN_GLDS
+
+  // ---- fragment read offsets (same image and swizzle as the BM x 256 kernel)
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2 * TQ], b_off[4];
+#pragma unroll
+  for (int t = 0; t < 2 * TQ; ++t) {
+    const int row = wm * (BM / 2) + t * 16 + fr;
+    a_off[t] = row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = wn * 64 + t * 16 + fr;
+    b_off[t] = 2 * A_TILE + row * 64 + ((fq ^ ((0 - (row >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[2 * TQ][4];
+#pragma unroll
+  for (int i = 0; i < 2 * TQ; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = CONV ? p.ldb / BK3 : p.K / BK3;
+  V8 ah[TQ], al[TQ], bh[2], bl[2];
+  auto read_a = [&](const char* s0, int qa) {
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+      ah[t] = *(const V8*)(s0 + a_off[qa * TQ + t]);
+      al[t] = *(const V8*)(s0 + A_TILE + a_off[qa * TQ + t]);
+      if constexpr (RELU_A) { ah[t] = relu8(ah[t]); al[t] = relu8(al[t]); }
+    }
+  };
+  auto read_b = [&](const char* s0, int qb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bh[t] = *(const V8*)(s0 + b_off[qb * 2 + t]);
+      bl[t] = *(const V8*)(s0 + W_TILE + b_off[qb * 2 + t]);
+    }
+  };
+  auto quad = [&](int qa, int qb) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 c = acc[qa * TQ + i][qb * 2 + j];
+        c = H::mfma16(bh[j], al[i], c);
+        c = H::mfma16(bl[j], ah[i], c);
+        c = H::mfma16(bh[j], ah[i], c);
+        acc[qa * TQ + i][qb * 2 + j] = c;
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // one phase: [fragment reads, DMA issue, counted wait] barrier [MFMAs] barrier
+// counted wait: all but the two newest units (VA for waves that carry 2 pieces of an A unit, VB for BM 192's
+// waves 4-7 that carry one)
+#define VDN_PHASE(READS, ISSUE, VA, VB, QA, QB)                  \
+  do {                                                           \
+    READS;                                                       \
+    ISSUE;                                                       \
+    if (a_both) asm volatile("s_waitcnt vmcnt(" #VA ")" ::: "memory");  \
+    else asm volatile("s_waitcnt vmcnt(" #VB ")" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    quad(QA, QB);                                                \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    __builtin_amdgcn_s_barrier();                                \
+  } while (0)
+  constexpr std::integral_constant<int, 0> U0{};
+  constexpr std::integral_constant<int, 1> U1{};
+  constexpr std::integral_constant<int, 2> U2{};
+  constexpr std::integral_constant<int, 3> U3{};
+
+  // prologue: the whole first K tile
+  issue(U0, 0, 0);
+  issue(U1, 0, 0);
+  issue(U2, 0, 0);
+  issue(U3, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind
+
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const char* sc = smem + (kt & 1) * STAGE;
+    const int nb = (kt + 1) & 1;
+    VDN_PHASE((read_a(sc, 0), read_b(sc, 0)), issue(U0, nb, kt + 1), 4, 2, 0, 0);
+    VDN_PHASE(read_b(sc, 1), issue(U1, nb, kt + 1), 4, 3, 0, 1);
+    VDN_PHASE(read_a(sc, 1), issue(U2, nb, kt + 1), 4, 4, 1, 1);
+    VDN_PHASE(read_b(sc, 0), issue(U3, nb, kt + 1), 4, 3, 1, 0);
+  }
+  {
+    const char* sc = smem + ((nk - 1) & 1) * STAGE;
+    VDN_PHASE((read_a(sc, 0), read_b(sc, 0)), (void)0, 2, 1, 0, 0);
+    VDN_PHASE(read_b(sc, 1), (void)0, 0, 0, 0, 1);
+    VDN_PHASE(read_a(sc, 1), (void)0, 0, 0, 1, 1);
+    VDN_PHASE(read_b(sc, 0), (void)0, 0, 0, 1, 0);
+  }
+#undef VDN_PHASE
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
+
+  epilogue_regs<DT, 2 * TQ, 4, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
 template <int DT, int BM, int BN, int WM, int WN>
@@ -883,14 +1254,45 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
       hipLaunchKernelGGL((gemm_x3_big_kernel<DT, AM, BM, ST, false>), g, b, lds, s, d);                 \
     }                                                                                                   \
   } while (0)
+  // straight-line epilogue flavours exist for the plain-A kernels at BM 256 / 192 (the encoder / memory linears)
+  const int fl = (BM >= 192 && d.a_mode != VDN_A_CONV3X3) ? epi_flavour(d) : d.store;
+  if constexpr (BM == 256 || BM == 192) {  // ping-pong 8-phase kernel (VDN_GEMM_P8=0 falls back to the lock-step one)
+    // measured (tools/gemm_bench.py): the ping-pong loop runs at 97 % of the clock-limited MFMA rate at BM 256
+    // (24 MFMAs cover a load segment) but not at BM 192 (18 do not), where the lock-step PIPE loop is as fast:
+    // default = BM 256 only; VDN_GEMM_P8=2 also BM 192, =0 never.
+    static const int p8 = getenv("VDN_GEMM_P8") ? atoi(getenv("VDN_GEMM_P8")) : 1;
+    if (p8 >= (BM == 256 ? 1 : 2)) {
+#define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g, b, lds, s, d)
+      if (d.a_mode == VDN_A_CONV3X3) {
+        if (d.relu_a) VDN_LAUNCH_P8(2, VDN_ST_PLAIN);
+        else VDN_LAUNCH_P8(1, VDN_ST_PLAIN);
+      } else {
+        switch (fl) {
+          case VDN_ST_PLAIN: VDN_LAUNCH_P8(0, VDN_ST_PLAIN); break;
+          case VDN_ST_CONVT: VDN_LAUNCH_P8(0, VDN_ST_CONVT); break;
+          case VDN_ST_GEGLU: VDN_LAUNCH_P8(0, VDN_ST_GEGLU); break;
+          case VDN_STX_FC1: VDN_LAUNCH_P8(0, VDN_STX_FC1); break;
+          case VDN_STX_RES: VDN_LAUNCH_P8(0, VDN_STX_RES); break;
+          case VDN_STX_HEADS: VDN_LAUNCH_P8(0, VDN_STX_HEADS); break;
+          default: VDN_LAUNCH_P8(0, VDN_ST_HEADS); break;
+        }
+      }
+#undef VDN_LAUNCH_P8
+      VDN_CHECK_LAUNCH();
+      return VDN_OK;
+    }
+  }
   if (d.a_mode == VDN_A_CONV3X3) {  // convolutions always store plain NHWC rows
     if (d.relu_a) VDN_LAUNCH_BIG(2, VDN_ST_PLAIN);
     else VDN_LAUNCH_BIG(1, VDN_ST_PLAIN);
   } else {
-    switch (d.store) {
+    switch (fl) {
       case VDN_ST_PLAIN: VDN_LAUNCH_BIG(0, VDN_ST_PLAIN); break;
       case VDN_ST_CONVT: VDN_LAUNCH_BIG(0, VDN_ST_CONVT); break;
       case VDN_ST_GEGLU: VDN_LAUNCH_BIG(0, VDN_ST_GEGLU); break;
+      case VDN_STX_FC1: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_FC1); } break;
+      case VDN_STX_RES: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_RES); } break;
+      case VDN_STX_HEADS: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_HEADS); } break;
       default: VDN_LAUNCH_BIG(0, VDN_ST_HEADS); break;
     }
   }
