@@ -36,11 +36,20 @@ constexpr int BK = 64;
 // load inside the store loop waits on vmcnt, which on gfx9 also counts the stores issued before it, so
 // every group paid a full store round trip (measured: 10 us of "math" per tile round that was latency).
 // internal store codes (never in a descriptor): specialised epilogues, see emit4 / epi_flavour
-constexpr int VDN_STX_FC1 = 100, VDN_STX_RES = 101, VDN_STX_HEADS = 102;
+constexpr int VDN_STX_FC1 = 100, VDN_STX_RES = 101, VDN_STX_HEADS = 102, VDN_STX_HALF = 103, VDN_STX_RESHALF1 = 104,
+              VDN_STX_RESHALF2 = 105;
 
 // Which straight-line flavour (if any) computes exactly what descriptor `d` asks for.
-inline int epi_flavour(const vdn_gemm_desc& d) {
+__host__ __device__ inline int epi_flavour(const vdn_gemm_desc& d) {
   const bool half_out = d.out_dt != VDN_F32;
+  const bool plain_rows = d.store == VDN_ST_PLAIN && !d.rowadd && !d.gamma && !d.tab && d.row_group <= 0;
+  if (plain_rows && half_out && d.out_lo && d.act != VDN_ACT_GELU) {
+    if (!d.res1 && !d.res2) return VDN_STX_HALF;  // [bias] [relu] -> split half planes (1x1 / 3x3 convolutions)
+    if (d.act == VDN_ACT_NONE && d.res1 && d.res1_lo && d.res1_dt == d.out_dt) {
+      if (!d.res2) return VDN_STX_RESHALF1;
+      if (d.res2_lo && d.res2_dt == d.out_dt) return VDN_STX_RESHALF2;
+    }
+  }
   if (d.store == VDN_ST_PLAIN && d.bias && d.act == VDN_ACT_GELU && !d.rowadd && !d.gamma && !d.tab && !d.res1 && !d.res2 &&
       half_out && d.out_lo && d.row_group <= 0)
     return VDN_STX_FC1;
@@ -66,6 +75,36 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
   // per SIMD those scalar branches were 12 us of every 31 us tile round at K = 32 (tools/gemm_ablate.sh).
   if constexpr (STORE == VDN_STX_FC1) {  // bias + GELU -> split half planes, plain rows
     a = gelu4(a + bias_a);
+    const size_t o = (size_t)m * p.ldc + n;
+    typename H::V4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      T h0, h1, l0, l1;
+      split2_rtz(a[e], a[e + 1], h0, h1, l0, l1);
+      h[e] = h0; h[e + 1] = h1; l[e] = l0; l[e + 1] = l1;
+    }
+    *(typename H::V4*)((T*)p.out + o) = h;
+    *(typename H::V4*)((T*)p.out_lo + o) = l;
+    return;
+  } else if constexpr (STORE == VDN_STX_HALF || STORE == VDN_STX_RESHALF1 || STORE == VDN_STX_RESHALF2) {
+    // [bias] [relu] [+ split-half residual(s)] -> split half planes, plain rows (the DPT head's convolutions)
+    a += bias_a;
+    if constexpr (STORE == VDN_STX_HALF) {
+      const float floor_v = p.act == VDN_ACT_RELU ? 0.f : -INFINITY;  // branch-free optional ReLU
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], floor_v);
+    } else {
+      const size_t r1 = (size_t)m * p.ldr1 + n;
+      const typename H::V4 rh = *(const typename H::V4*)((const T*)p.res1 + r1), rl = *(const typename H::V4*)((const T*)p.res1_lo + r1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += (float)rh[e] + (float)rl[e];
+      if constexpr (STORE == VDN_STX_RESHALF2) {
+        const size_t r2 = (size_t)m * p.ldr2 + n;
+        const typename H::V4 qh = *(const typename H::V4*)((const T*)p.res2 + r2), ql = *(const typename H::V4*)((const T*)p.res2_lo + r2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += (float)qh[e] + (float)ql[e];
+      }
+    }
     const size_t o = (size_t)m * p.ldc + n;
     typename H::V4 h, l;
 #pragma unroll
@@ -289,11 +328,16 @@ __device__ __forceinline__ void epilogue_wave_lds(f32x4 (&acc)[TM][4], const vdn
 
 template <int DT, int TM, int TN>
 __device__ __forceinline__ void epilogue_dispatch(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
-  switch (p.store) {
+  switch (epi_flavour(p)) {
+    case VDN_STX_HALF: epilogue_regs<DT, TM, TN, VDN_STX_HALF>(acc, p, mw, nw, lane); break;
+    case VDN_STX_RESHALF1: epilogue_regs<DT, TM, TN, VDN_STX_RESHALF1>(acc, p, mw, nw, lane); break;
+    case VDN_STX_RESHALF2: epilogue_regs<DT, TM, TN, VDN_STX_RESHALF2>(acc, p, mw, nw, lane); break;
+    case VDN_STX_RES: epilogue_regs<DT, TM, TN, VDN_STX_RES>(acc, p, mw, nw, lane); break;
+    case VDN_STX_FC1:
     case VDN_ST_PLAIN: epilogue_regs<DT, TM, TN, VDN_ST_PLAIN>(acc, p, mw, nw, lane); break;
     case VDN_ST_CONVT: epilogue_regs<DT, TM, TN, VDN_ST_CONVT>(acc, p, mw, nw, lane); break;
     case VDN_ST_GEGLU: epilogue_regs<DT, TM, TN, VDN_ST_GEGLU>(acc, p, mw, nw, lane); break;
-    default: epilogue_regs<DT, TM, TN, VDN_ST_HEADS>(acc, p, mw, nw, lane); break;
+    default: epilogue_regs<DT, TM, TN, VDN_ST_HEADS>(acc, p, mw, nw, lane); break;  // VDN_ST_HEADS, VDN_STX_HEADS
   }
 }
 
@@ -1255,7 +1299,12 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     }                                                                                                   \
   } while (0)
   // straight-line epilogue flavours exist for the plain-A kernels at BM 256 / 192 (the encoder / memory linears)
-  const int fl = (BM >= 192 && d.a_mode != VDN_A_CONV3X3) ? epi_flavour(d) : d.store;
+  int fl = epi_flavour(d);
+  if (d.a_mode == VDN_A_CONV3X3) {
+    if (fl != VDN_STX_HALF && fl != VDN_STX_RESHALF1 && fl != VDN_STX_RESHALF2) fl = VDN_ST_PLAIN;
+  } else if (BM < 192 || fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) {
+    fl = d.store;
+  }
   if constexpr (BM == 256 || BM == 192) {  // ping-pong 8-phase kernel (VDN_GEMM_P8=0 falls back to the lock-step one)
     // measured (tools/gemm_bench.py): the ping-pong loop runs at 97 % of the clock-limited MFMA rate at BM 256
     // (24 MFMAs cover a load segment) but not at BM 192 (18 do not), where the lock-step PIPE loop is as fast:
@@ -1264,11 +1313,18 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     if (p8 >= (BM == 256 ? 1 : 2)) {
 #define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g, b, lds, s, d)
       if (d.a_mode == VDN_A_CONV3X3) {
-        if (d.relu_a) VDN_LAUNCH_P8(2, VDN_ST_PLAIN);
-        else VDN_LAUNCH_P8(1, VDN_ST_PLAIN);
+#define VDN_CONV_P8(ST) do { if (d.relu_a) VDN_LAUNCH_P8(2, ST); else VDN_LAUNCH_P8(1, ST); } while (0)
+        switch (fl) {
+          case VDN_STX_HALF: VDN_CONV_P8(VDN_STX_HALF); break;
+          case VDN_STX_RESHALF1: VDN_CONV_P8(VDN_STX_RESHALF1); break;
+          case VDN_STX_RESHALF2: VDN_CONV_P8(VDN_STX_RESHALF2); break;
+          default: VDN_CONV_P8(VDN_ST_PLAIN); break;
+        }
+#undef VDN_CONV_P8
       } else {
         switch (fl) {
           case VDN_ST_PLAIN: VDN_LAUNCH_P8(0, VDN_ST_PLAIN); break;
+          case VDN_STX_HALF: VDN_LAUNCH_P8(0, VDN_STX_HALF); break;
           case VDN_ST_CONVT: VDN_LAUNCH_P8(0, VDN_ST_CONVT); break;
           case VDN_ST_GEGLU: VDN_LAUNCH_P8(0, VDN_ST_GEGLU); break;
           case VDN_STX_FC1: VDN_LAUNCH_P8(0, VDN_STX_FC1); break;
@@ -1283,11 +1339,18 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     }
   }
   if (d.a_mode == VDN_A_CONV3X3) {  // convolutions always store plain NHWC rows
-    if (d.relu_a) VDN_LAUNCH_BIG(2, VDN_ST_PLAIN);
-    else VDN_LAUNCH_BIG(1, VDN_ST_PLAIN);
+#define VDN_CONV_BIG(ST) do { if (d.relu_a) VDN_LAUNCH_BIG(2, ST); else VDN_LAUNCH_BIG(1, ST); } while (0)
+    switch (fl) {
+      case VDN_STX_HALF: VDN_CONV_BIG(VDN_STX_HALF); break;
+      case VDN_STX_RESHALF1: VDN_CONV_BIG(VDN_STX_RESHALF1); break;
+      case VDN_STX_RESHALF2: VDN_CONV_BIG(VDN_STX_RESHALF2); break;
+      default: VDN_CONV_BIG(VDN_ST_PLAIN); break;
+    }
+#undef VDN_CONV_BIG
   } else {
     switch (fl) {
       case VDN_ST_PLAIN: VDN_LAUNCH_BIG(0, VDN_ST_PLAIN); break;
+      case VDN_STX_HALF: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_HALF); } break;
       case VDN_ST_CONVT: VDN_LAUNCH_BIG(0, VDN_ST_CONVT); break;
       case VDN_ST_GEGLU: VDN_LAUNCH_BIG(0, VDN_ST_GEGLU); break;
       case VDN_STX_FC1: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_FC1); } break;
