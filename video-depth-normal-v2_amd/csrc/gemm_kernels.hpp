@@ -288,6 +288,31 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_ge
     bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     gam4[j] = (p.gamma && n < p.N) ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
   }
+  if constexpr (STORE == VDN_STX_RES) {
+    // residual rows are fetched one 16-row slab AHEAD of the stores: a load issued after a store waits for
+    // that store's acknowledgement (vmcnt counts both on gfx9), which serialised every group on a round trip
+    f32x4 r[2][TN];
+    auto fetch = [&](int i, f32x4 (&dst)[TN]) {
+      const int m = mw + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 16 + fq * 4;
+        dst[j] = (m < p.M && n < p.N) ? *(const f32x4*)((const float*)p.res1 + (size_t)m * p.ldr1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    fetch(0, r[0]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i + 1 < TM) fetch(i + 1, r[(i + 1) & 1]);
+      const int m = mw + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 16 + fq * 4;
+        if (m < p.M && n < p.N) *(f32x4*)((float*)p.out + (size_t)m * p.ldc + n) = (acc[i][j] + bias4[j]) * gam4[j] + r[i & 1][j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
