@@ -476,11 +476,14 @@ def test_x3_heads_rope_and_flash(rt3):
     close(out.float().reshape(B, P, C), ref, 1e-5)
 
 
-@pytest.mark.parametrize("nq,nk", [(150, 200), (1370, 1370)])
-def test_x3_flash_attention(rt3, nq, nk):
+@pytest.mark.parametrize("nq,nk,gain", [(150, 200, 1.0), (1370, 1370, 1.0), (37, 64, 1.0), (70, 128, 1.0), (100, 130, 1.0),
+                                        (129, 777, 6.0)])
+def test_x3_flash_attention(rt3, nq, nk, gain):
+    """1 / 2 / 3 / many key tiles (the software pipeline's prologue, peeled first and last iterations), ragged
+    last tile; gain 6 makes row maxima jump by far more than the lazy-rescale threshold between tiles."""
     from vdn.runtime import ceil_to
     B, H = 1, 2
-    q, k, v = rnd(B, H, nq, 64, seed=230), rnd(B, H, nk, 64, seed=231), rnd(B, H, nk, 64, seed=232)
+    q, k, v = rnd(B, H, nq, 64, seed=230, scale=gain), rnd(B, H, nk, 64, seed=231), rnd(B, H, nk, 64, seed=232)
     ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(1, 2).reshape(B, nq, H * 64)
     qp, kp = ceil_to(nq, 64), ceil_to(nk, 64)
     qd, kd, vd = rt3.hbuf("t2_q", (B * H, qp, 64), zero=True), rt3.hbuf("t2_k", (B * H, kp, 64), zero=True), rt3.hbuf("t2_v", (B * H, 64, kp), zero=True)
@@ -494,6 +497,10 @@ def test_x3_flash_attention(rt3, nq, nk):
     out = rt3.hbuf("t2_o", (B * nq, H * 64))
     rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
     close(out.float().reshape(B, nq, H * 64), ref, 1e-5)
+    first = (out.hi.clone(), out.lo.clone())
+    for _ in range(3):  # bitwise repeatable (race screen for the LDS ring / counted waits)
+        rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
+        assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
 
 
 def test_x3_temporal_norms_upsample_headout(rt3):
@@ -605,3 +612,48 @@ def test_x3_big_tile_k_smaller_than_padded_stride_with_poisoned_neighbour(rt3, m
     out = torch.empty(M, N, device=DEV)
     rt3.gemm(A, pack.linear(w.to(DEV), rt3.prec), M, N, K, out=out)
     close(out, (a.double() @ w.double().t()).float(), 3e-6)
+
+
+@pytest.mark.parametrize("p8,bm", [("1", "256"), ("2", "192")])
+@pytest.mark.parametrize("K", [32, 64, 160])
+def test_x3_pingpong_gemm_short_k_and_repeatability(rt3, p8, bm, K, monkeypatch):
+    """The 8-phase ping-pong kernel with 1, 2 and 5 K tiles (prologue only / drain counts 2,0 / steady state),
+    ragged M and N, run 8 times: every run must be bitwise identical (a counted-vmcnt or barrier-parity
+    mistake shows up as rare differing tiles long before it shows up as a wrong mean)."""
+    from vdn import pack, _abi
+    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    monkeypatch.setenv("VDN_GEMM_P8", p8)
+    M, N = 1370 + 77, 1024 + 200
+    a = rnd(M, K, seed=330)
+    w = rnd(N, K, seed=331, scale=1 / math.sqrt(K))
+    b = rnd(N, seed=332)
+    ref = F.gelu(a.double() @ w.double().t() + b.double()).float()
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    oh = rt3.hbuf(f"t_p8_{K}", (M, N))
+    rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU)
+    close(oh.float(), ref, 3e-6)
+    first = (oh.hi.clone(), oh.lo.clone())
+    for _ in range(7):
+        rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU)
+        assert torch.equal(oh.hi, first[0]) and torch.equal(oh.lo, first[1])
+
+
+@pytest.mark.parametrize("bm", ["128", "192", "256"])
+@pytest.mark.parametrize("two", [False, True])
+def test_x3_conv_residual_plane_flavours(rt3, bm, two, monkeypatch):
+    """3x3 conv + bias + one / two split-half residuals -> split-half output (the ResidualConvUnit's second conv:
+    the straight-line epilogue flavours) on every 8-wave tile height, against fp64."""
+    from vdn import pack
+    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    B, H, W, Ci, Co = 2, 41, 37, 64, 256
+    x = rnd(B, H, W, Ci, seed=340)
+    w = rnd(Co, Ci, 3, 3, seed=341, scale=1 / math.sqrt(9 * Ci))
+    b = rnd(Co, seed=342)
+    r1, r2 = rnd(B * H * W, Co, seed=343), rnd(B * H * W, Co, seed=344)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ref = (ref + r1.double() + (r2.double() if two else 0)).float()
+    out = rt3.hbuf(f"t_crf_{bm}", (B * H * W, Co))
+    rt3.gemm(rt3.to_half(x.reshape(-1, Ci).to(DEV)), pack.conv3x3(w.to(DEV), rt3.prec), B * H * W, Co, 9 * Ci, out=out,
+             bias=b.to(DEV), res1=rt3.to_half(r1.to(DEV)), res2=rt3.to_half(r2.to(DEV)) if two else None,
+             conv=dict(B=B, H=H, W=W, C=Ci, OH=H, OW=W, stride=1))
+    close(out.float(), ref, 5e-6)

@@ -94,31 +94,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   // ---- staging: 8 pieces (1 KiB = 8 rows) per tile and operand, 2 per wave
+  // wave-uniform tile base (SGPR pair) + loop-invariant 32-bit lane offsets: no per-tile VALU address math
   const int lr = lane >> 3;
-  const size_t kbase = (size_t)bh * nk_pad * 64;
-  const size_t vbase = (size_t)bh * 64 * nk_pad;
+  const T* Kb = K + (size_t)bh * nk_pad * 64;
+  const T* Vb = Vt + (size_t)bh * 64 * nk_pad;
+  const ptrdiff_t kl_delta = SPLIT ? (const char*)Kl - (const char*)K : 0;
+  const ptrdiff_t vl_delta = SPLIT ? (const char*)Vtl - (const char*)Vt : 0;
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 4 * i) * 8 + lr;
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    koff[i] = (unsigned)(row * 64 + c * 8);
+    voff[i] = (unsigned)(row * nk_pad + c * 8);
+  }
   auto stage_k = [&](int buf, int t) {
     char* sK = smem + buf * NT * TILE;
+    const T* kt = Kb + (size_t)t * 4096;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 4 * i;
-      const int row = pc * 8 + lr;
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      const size_t ko = kbase + (size_t)(t * 64 + row) * 64 + c * 8;
-      GLDS16(K + ko, sK + pc * 1024);
-      if constexpr (SPLIT) GLDS16(Kl + ko, sK + 2 * TILE + pc * 1024);
+      GLDS16(kt + koff[i], sK + pc * 1024);
+      if constexpr (SPLIT) GLDS16((const char*)(kt + koff[i]) + kl_delta, sK + 2 * TILE + pc * 1024);
     }
   };
   auto stage_v = [&](int buf, int t) {
     char* sV = smem + buf * NT * TILE + TILE;
+    const T* vt = Vb + (size_t)t * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 4 * i;
-      const int row = pc * 8 + lr;
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      const size_t vo = vbase + (size_t)row * nk_pad + t * 64 + c * 8;
-      GLDS16(Vt + vo, sV + pc * 1024);
-      if constexpr (SPLIT) GLDS16(Vtl + vo, sV + 2 * TILE + pc * 1024);
+      GLDS16(vt + voff[i], sV + pc * 1024);
+      if constexpr (SPLIT) GLDS16((const char*)(vt + voff[i]) + vl_delta, sV + 2 * TILE + pc * 1024);
     }
   };
 
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1]));
     if constexpr (SPLIT) asm volatile("" : "+v"(pl[0][0]), "+v"(pl[0][1]), "+v"(pl[1][0]), "+v"(pl[1][1]));
     if (bump) {  // O is in the old reference (it just received tile t-1): move it to the new one
+      asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch: if-converted it costs 16 v_pk_mul per tile
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
     }

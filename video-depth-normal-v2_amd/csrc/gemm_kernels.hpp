@@ -1311,7 +1311,7 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + 255) / 256);
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * 256 * 64);
   const dim3 g(tiles), b(512);
-  static const bool no_pipe = getenv("VDN_GEMM_NOPIPE") != nullptr;
+  const bool no_pipe = getenv("VDN_GEMM_NOPIPE") != nullptr;
   constexpr bool CAN_PIPE = BM <= 192;  // BM = 256 has no registers for the second W fragment set
   const bool pipe = CAN_PIPE && !no_pipe;
 #define VDN_LAUNCH_BIG(AM, ST)                                                                          \
@@ -1334,7 +1334,8 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     // measured (tools/gemm_bench.py): the ping-pong loop runs at 97 % of the clock-limited MFMA rate at BM 256
     // (24 MFMAs cover a load segment) but not at BM 192 (18 do not), where the lock-step PIPE loop is as fast:
     // default = BM 256 only; VDN_GEMM_P8=2 also BM 192, =0 never.
-    static const int p8 = getenv("VDN_GEMM_P8") ? atoi(getenv("VDN_GEMM_P8")) : 1;
+    const char* p8e = getenv("VDN_GEMM_P8");  // read per launch: tests flip it
+    const int p8 = p8e ? atoi(p8e) : 1;
     if (p8 >= (BM == 256 ? 1 : 2)) {
 #define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g, b, lds, s, d)
       if (d.a_mode == VDN_A_CONV3X3) {
