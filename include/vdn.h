@@ -203,6 +203,19 @@ int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const floa
 int vdn_addtab_cast(int dt, const float* x, const float* tab, int tab_div, int tab_mod, void* y, void* y_lo,
                     size_t rows, int C, vdn_stream stream);
 
+/* Device-side window stitcher of VideoDepthAnything.infer_video_depth (video_depth.py:118-156):
+ * vdn_stitch_fit   — closed-form least-squares scale/shift of `pred` onto `target` over n f32 values with an all-ones
+ *                    mask (compute_scale_and_shift_full, utils/util.py:40-62): coef[0..1] = {scale, shift}, {1, 0} when
+ *                    the normal matrix is singular. Deterministic fp64 sums; `workspace` = vdn_stitch_workspace_bytes().
+ * vdn_stitch_apply — for a window [T, hw] f32: frames align_len..overlap-1 are clamped-affine-mapped and cross-faded
+ *                    into out_tail[overlap-align_len, hw] with weights 0, 1/(n-1), .., 1 (get_interpolate_frames,
+ *                    utils/util.py:65-73), frames overlap..T-1 are mapped into out_new, and the mapped frame
+ *                    `ref_frame` is also written to ref1 (the moving second alignment target, video_depth.py:150-152). */
+size_t vdn_stitch_workspace_bytes(void);
+int vdn_stitch_fit(const float* pred, const float* target, size_t n, void* workspace, float* coef, vdn_stream stream);
+int vdn_stitch_apply(const float* window, const float* coef, float* out_tail, float* out_new, float* ref1, size_t hw,
+                     int T, int align_len, int overlap, int ref_frame, vdn_stream stream);
+
 /* misc */
 int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);
 size_t vdn_sizeof_gemm_desc(void);      /* layout probes for FFI bindings */

@@ -139,6 +139,15 @@ def test_infer_video_depth_windows_and_stitch():
     frames = synth.frames_u8(1234, 40, 140, 140)
     d, fps = model.infer_video_depth(frames, 24, input_size=140)
     assert d.shape == (40, 140, 140) and fps == 24 and np.isfinite(d).all() and (d >= 0).all()
+    # the on-device stitcher against the host restatement applied to the same per-window outputs
+    from vdn import util
+    net = model.preprocess_frames(frames, 140)
+    per_window = []
+    for idxs in util.window_table(40):
+        w = model.forward(net[torch.tensor(idxs, device=net.device)][None])[0].cpu().numpy()
+        per_window += [w[i] for i in range(32)]
+    host = util.stitch(per_window, 40)
+    assert np.allclose(d, host, rtol=2e-5, atol=1e-6), float(np.abs(d - host).max())
 
 
 def test_infer_image_shape():

@@ -657,3 +657,29 @@ def test_x3_conv_residual_plane_flavours(rt3, bm, two, monkeypatch):
              bias=b.to(DEV), res1=rt3.to_half(r1.to(DEV)), res2=rt3.to_half(r2.to(DEV)) if two else None,
              conv=dict(B=B, H=H, W=W, C=Ci, OH=H, OW=W, stride=1))
     close(out.float(), ref, 5e-6)
+
+
+@pytest.mark.parametrize("nw,fh,fw", [(1, 20, 24), (2, 37, 41), (4, 30, 33)])
+def test_device_stitcher_matches_host_restatement(rt, nw, fh, fw):
+    """vdn_stitch_fit / vdn_stitch_apply (the on-device window stitcher) against vdn.util.stitch, the host
+    restatement of video_depth.py:118-156 that tests/test_host.py pins to the reference's own run."""
+    from vdn import util
+    from vdn.video_depth import DeviceStitcher
+    wins = [(rnd(32, fh, fw, seed=400 + w).abs() * (1.0 + 0.3 * w) + 0.1 * w) for w in range(nw)]
+    n = 32 + 22 * (nw - 1) - 5
+    ref = util.stitch([w_[i].numpy() for w_ in wins for i in range(32)], n)
+    st = DeviceStitcher(rt, nw, fh, fw)
+    for w_ in wins:
+        st.push(w_.to(DEV))
+    got = st.result(n).cpu()
+    assert got.shape == ref.shape
+    close(got, torch.from_numpy(ref), 2e-6)
+
+
+def test_device_stitcher_singular_fit_is_identity(rt):
+    """all-equal alignment frames make the 2x2 normal matrix singular: scale 1, shift 0 (utils/util.py:55-56)."""
+    pred = torch.full((2, 16, 16), 3.0, device=DEV)
+    coef = torch.empty(2, device=DEV)
+    rt.stitch_fit(pred, pred.clone(), coef)
+    # a00*a11 - a01^2 = (9n)(n) - (3n)^2 = 0
+    assert coef.cpu().tolist() == [1.0, 0.0]

@@ -86,6 +86,12 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
     dev = mine[0].device if mine else (net.device if prep else torch.device("cpu"))
     local = torch.stack(mine) if mine else torch.zeros((0, util.INFER_LEN, fh, fw), device=dev)
     allw = gather_windows(local.float().contiguous(), len(table), group)
+    if allw.is_cuda and hasattr(model, "_engines"):  # stitch on the device, one D2H per clip
+        from .video_depth import DeviceStitcher
+        st = DeviceStitcher(model._engines()["rt"], len(table), fh, fw)
+        for w in range(len(table)):
+            st.push(allw[w])
+        return st.result(n).cpu().numpy(), target_fps
     dn = allw.cpu().numpy()
     depth_list = [dn[w, i] for w in range(len(table)) for i in range(util.INFER_LEN)]
     return util.stitch(depth_list, n), target_fps

@@ -250,6 +250,20 @@ class Runtime:
     def upsample_f32(self, x, y, B: int, IH: int, IW: int, OH: int, OW: int, relu: bool = False):
         self._launch(abi.lib.vdn_upsample_bilinear_f32, x.data_ptr(), y.data_ptr(), B, IH, IW, OH, OW, int(relu))
 
+    def stitch_fit(self, pred: torch.Tensor, target: torch.Tensor, coef: torch.Tensor):
+        """coef[0:2] <- least-squares (scale, shift) of pred onto target (utils/util.py:40-62), on the device."""
+        ws = self.buf("stitch_ws", (abi.lib.vdn_stitch_workspace_bytes() // 8,), torch.float64)
+        assert pred.is_contiguous() and target.is_contiguous() and pred.numel() == target.numel()
+        self._launch(abi.lib.vdn_stitch_fit, pred.data_ptr(), target.data_ptr(), pred.numel(), ws.data_ptr(), coef.data_ptr())
+
+    def stitch_apply(self, window: torch.Tensor, coef: torch.Tensor, out_tail: torch.Tensor, out_new: torch.Tensor,
+                     ref1: torch.Tensor, align_len: int, overlap: int, ref_frame: int):
+        T, hw = window.shape[0], window[0].numel()
+        assert window.is_contiguous() and out_tail.is_contiguous() and out_new.is_contiguous() and ref1.is_contiguous()
+        assert out_tail.shape[0] == overlap - align_len and out_new.shape[0] == T - overlap
+        self._launch(abi.lib.vdn_stitch_apply, window.data_ptr(), coef.data_ptr(), out_tail.data_ptr(), out_new.data_ptr(),
+                     ref1.data_ptr(), hw, T, align_len, overlap, ref_frame)
+
     def patchify(self, img, rows, B: int, H: int, W: int, ldk: int):
         rows, rl = _hl(rows)
         self._launch(abi.lib.vdn_patchify, self.dt, img.data_ptr(), rows.data_ptr(), rl, B, H, W, ldk)

@@ -137,10 +137,42 @@ class VideoDepthAnything(_EngineOwner):
             input_size = round(input_size / 14) * 14
         n = frames.shape[0]
         net_in = self.preprocess_frames(frames, input_size)  # [n,3,H,W]
-        depth_list = []
+        st = DeviceStitcher(rt, len(util.window_table(n)), fh, fw)
         for idxs in util.window_table(n):
             cur = net_in[torch.tensor(idxs, device=rt.device)][None]
-            d = self.resize_depth(self.forward(cur)[0], fh, fw)  # [32,fh,fw]
-            dn = d.cpu().numpy()
-            depth_list += [dn[i] for i in range(INFER_LEN)]
-        return util.stitch(depth_list, n), target_fps
+            st.push(self.resize_depth(self.forward(cur)[0], fh, fw))  # [32,fh,fw], stays on the device
+        return st.result(n).cpu().numpy(), target_fps  # the clip's only device-to-host copy
+
+
+class DeviceStitcher:
+    """video_depth.py:118-156 on the device: every window after the first is affine-aligned to
+    the running result on the two alignment frames (least-squares scale/shift, `vdn_stitch_fit`), clamped at 0,
+    cross-faded over the 8 interpolation frames and appended (`vdn_stitch_apply`). No host synchronisation until
+    `result()` is copied; `vdn/util.stitch` is the host restatement the tests compare against."""
+
+    def __init__(self, rt, n_windows: int, fh: int, fw: int):
+        self.rt = rt
+        self.align = OVERLAP - INTERP_LEN
+        self.step = INFER_LEN - OVERLAP
+        self.out = torch.empty((INFER_LEN + self.step * (n_windows - 1), fh, fw), dtype=torch.float32, device=rt.device)
+        self.ref = torch.empty((self.align, fh, fw), dtype=torch.float32, device=rt.device)
+        self.coef = torch.empty(2, dtype=torch.float32, device=rt.device)
+        self.length = 0
+
+    def push(self, d: torch.Tensor):
+        d = d.contiguous()
+        assert d.shape[0] == INFER_LEN and d.dtype == torch.float32
+        if self.length == 0:
+            self.out[:INFER_LEN].copy_(d)
+            for j, k in enumerate(KEYFRAMES[:self.align]):
+                self.ref[j].copy_(d[k])
+            self.length = INFER_LEN
+            return
+        assert self.align == 2, "the reference keeps ref[0] fixed and moves ref[1] (video_depth.py:150-152)"
+        self.rt.stitch_fit(d[:self.align], self.ref, self.coef)
+        self.rt.stitch_apply(d, self.coef, self.out[self.length - INTERP_LEN:self.length],
+                             self.out[self.length:self.length + self.step], self.ref[1], self.align, OVERLAP, KEYFRAMES[1])
+        self.length += self.step
+
+    def result(self, org_len: int) -> torch.Tensor:
+        return self.out[:org_len]
