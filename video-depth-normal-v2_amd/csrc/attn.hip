@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float x = o[db][4 * g + e] * inv;
-          if constexpr (SPLIT) {
+          if (outl) {  // the output is written as planes whenever the caller passes a lo plane (also in 1-product mode)
             T a, b2;
             split_rtz(x, a, b2);
             v[e] = a;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
         }
         *(typename HT::V4*)(out + oo + db * 32 + 8 * g + 4 * h) = v;
-        if constexpr (SPLIT) *(typename HT::V4*)(outl + oo + db * 32 + 8 * g + 4 * h) = vl;
+        if (outl) *(typename HT::V4*)(outl + oo + db * 32 + 8 * g + 4 * h) = vl;
       }
   }
 }
@@ -506,7 +506,7 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2, stag);
   else
     hipLaunchKernelGGL((flash_attn_kernel<DT, false>), grid, dim3(256), 32768 + extra, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                       (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, H, nq, nq_pad, nk,
+                       (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)outl, H, nq, nq_pad, nk,
                        nk_pad, sl2, stag);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
@@ -535,8 +535,9 @@ extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* 
   if (!Q || !K || !Vt || !out || B <= 0 || H <= 0 || nq <= 0 || nk <= 0) return VDN_EINVAL;
   if (nq_pad < nq || nk_pad < nk || (nk_pad & 63)) return VDN_EALIGN;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)out) & 15) return VDN_EALIGN;
-  const int nlo = (Q_lo != nullptr) + (K_lo != nullptr) + (Vt_lo != nullptr) + (out_lo != nullptr);
-  if (nlo != 0 && nlo != 4) return VDN_EINVAL;  // split precision is all-or-nothing here
+  const int nlo = (Q_lo != nullptr) + (K_lo != nullptr) + (Vt_lo != nullptr);
+  if (nlo != 0 && nlo != 3) return VDN_EINVAL;  // operand planes are all-or-nothing; the output may be split either way
+  if (nlo == 3 && !out_lo) return VDN_EINVAL;
   if (((uintptr_t)Q_lo | (uintptr_t)K_lo | (uintptr_t)Vt_lo | (uintptr_t)out_lo) & 15) return VDN_EALIGN;
   const float sl2 = scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;

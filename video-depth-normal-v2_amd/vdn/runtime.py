@@ -10,6 +10,8 @@ because buffers come from the arena by name).
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from contextlib import contextmanager
 from typing import Dict, List, Optional, Sequence, Tuple
