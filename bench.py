@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=7)
-    ap.add_argument("--workload", choices=["stream", "clip"], default="stream")
+    ap.add_argument("--workload", choices=["stream", "clip", "video"], default="stream")
+    ap.add_argument("--video-frames", type=int, default=256, help="video workload: clip length (BASELINE configs[3]: 256)")
     ap.add_argument("--batch", type=int, default=8, help="streams per GPU (stream) / frames per window (clip: 32)")
     ap.add_argument("--encoder", default="vitl")
     ap.add_argument("--precision", default=None, help="f16x3 (default, parity-green) | f16 | bf16x3 | bf16")
@@ -86,9 +87,12 @@ def main():
     if a.workload == "stream":
         model = vdn.DepthAnythingV2(**cfg)
         frames_per_step = a.batch
-    else:
+    elif a.workload == "clip":
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = 32
+    else:  # whole driver: u8 frames on the host -> windows -> device stitcher -> f32 depth on the host
+        model = vdn.VideoDepthAnything(**cfg)
+        frames_per_step = a.video_frames
     shapes = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
     sd = model.state_dict()
     sd.update(synth.fast_state_dict(shapes, 1234))
@@ -97,7 +101,12 @@ def main():
     prec_name, _ = _precision(a.precision)
     model.set_precision(prec_name)
 
-    fr = synth.frames_u8(1234 + rank, min(frames_per_step, 8), H, W)
+    fr = synth.frames_u8(1234 + (rank if a.workload != "video" else 0), min(frames_per_step, 8), H, W)
+    if a.workload == "video":
+        import numpy as np
+        from vdn import util
+        from vdn.dist import infer_video_depth_sharded
+        video = np.ascontiguousarray(np.tile(fr, ((frames_per_step + 7) // 8, 1, 1, 1))[:frames_per_step])
     x = torch.from_numpy(synth.normalize_frames(fr)).to(dev)
     if x.shape[0] < frames_per_step:
         x = x.repeat((frames_per_step + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:frames_per_step]
@@ -106,6 +115,10 @@ def main():
     x = x.contiguous()
 
     def step():
+        if a.workload == "video":  # windows are sharded over the ranks (strong scaling), every rank gets the result
+            if dist is not None:
+                return infer_video_depth_sharded(model, video, 24, input_size=518)[0]
+            return model.infer_video_depth(video, 24, input_size=518)[0]
         return model.forward(x)
 
     def sync_all():
@@ -143,7 +156,7 @@ def main():
     # region then runs without events, and the roofline figures come from K more steps of the same workload
     # issued on ONE lane right after it (state carried over, memory bank still full).
     dt, ev = timed(a.steps, (not a.no_kernel_events) and lanes == 1)
-    fps = frames_per_step * a.steps * n_gpus / dt
+    fps = frames_per_step * a.steps * (1 if a.workload == "video" else n_gpus) / dt
     dt1 = None
     if lanes > 1 and not a.no_kernel_events:
         os.environ["VDN_STREAMS"] = "1"
@@ -154,11 +167,15 @@ def main():
     out = {
         "metric": "depth frames/sec at 518x518, ViT-L" if enc == "vitl" else f"depth frames/sec at 518x518, {enc}",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+        "scaling": "strong" if a.workload == "video" else "weak", "vs_baseline": None,
         "dtype": prec_name, "data": "synthetic",
         "config": {"workload": ("DepthAnythingV2(%s) batch=%d 518x518 streams/GPU, memory bank full (S=6); replicas per GPU"
                                 % (enc, a.batch)) if a.workload == "stream" else
-                   "VideoDepthAnything(%s) one 32-frame 518x518 window per step; one window per GPU" % enc,
+                   ("VideoDepthAnything(%s) one 32-frame 518x518 window per step; one window per GPU" % enc) if a.workload == "clip" else
+                   ("VideoDepthAnything(%s).infer_video_depth on a %d-frame 518x518 u8 clip = %d windows of 32 (host frames in, "
+                    "host depth out: H2D, pre-processing, device stitcher and D2H inside the timed region); windows sharded over the GPUs"
+                    % (enc, frames_per_step, len(util.window_table(frames_per_step)))),
                    "frames_per_step_per_gpu": frames_per_step, "lanes": lanes, "precision": prec_name,
                    "precision_note": "f16x3 = fp16 hi/lo planes, 3 MFMA products per term (fp32-faithful, parity <=1e-3)"},
     }
@@ -166,7 +183,8 @@ def main():
     # ---------------- roofline of the dominant kernel (encoder linear GEMMs)
     if ev:
         C = vdn.modules.ENCODERS[enc]["dim"]
-        M = frames_per_step * (37 * 37 + 1)
+        per_launch = a.batch if a.workload == "stream" else 32  # frames one encoder launch covers
+        M = per_launch * (37 * 37 + 1)
         ms = [s.elapsed_time(e) for (tag, s, e) in ev if tag == "enc_linear"]
         if ms:
             avg_ms = sum(ms) / len(ms)
@@ -186,7 +204,7 @@ def main():
         att = [s.elapsed_time(e) for (tag, s, e) in ev if tag == "enc_attn"]
         if att:
             avg = sum(att) / len(att)
-            fl = 4.0 * frames_per_step * (C // 64) * 1370 * 1370 * 64
+            fl = 4.0 * per_launch * (C // 64) * 1370 * 1370 * 64
             nprod = 3 if prec_name.endswith("x3") else 1
             out["attention_kernel"] = {"avg_launch_ms": round(avg, 4), "achieved_tflops": round(fl / (avg * 1e-3) / 1e12, 2),
                                        "frac_of_mfma_peak": round(fl / (avg * 1e-3) / 1e12 / PEAK_TFLOPS_F16, 4),
