@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=7)
-    ap.add_argument("--workload", choices=["stream", "clip", "video"], default="stream")
+    ap.add_argument("--workload", choices=["stream", "clip", "video", "vstream"], default="stream")
     ap.add_argument("--video-frames", type=int, default=256, help="video workload: clip length (BASELINE configs[3]: 256)")
     ap.add_argument("--batch", type=int, default=8, help="streams per GPU (stream) / frames per window (clip: 32)")
     ap.add_argument("--encoder", default="vitl")
@@ -90,6 +90,9 @@ def main():
     elif a.workload == "clip":
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = 32
+    elif a.workload == "vstream":  # latency mode: one frame per step against the 31-frame projected K/V cache
+        model = vdn.VideoDepthAnything(**cfg)
+        frames_per_step = 1
     else:  # whole driver: u8 frames on the host -> windows -> device stitcher -> f32 depth on the host
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = a.video_frames
@@ -119,6 +122,8 @@ def main():
             if dist is not None:
                 return infer_video_depth_sharded(model, video, 24, input_size=518)[0]
             return model.infer_video_depth(video, 24, input_size=518)[0]
+        if a.workload == "vstream":
+            return model.stream_step(x[:1][None])
         return model.forward(x)
 
     def sync_all():
@@ -173,6 +178,8 @@ def main():
         "config": {"workload": ("DepthAnythingV2(%s) batch=%d 518x518 streams/GPU, memory bank full (S=6); replicas per GPU"
                                 % (enc, a.batch)) if a.workload == "stream" else
                    ("VideoDepthAnything(%s) one 32-frame 518x518 window per step; one window per GPU" % enc) if a.workload == "clip" else
+                   ("VideoDepthAnything(%s).stream_step: one 518x518 frame per step against 31 cached frames (projected K/V cache)" % enc)
+                   if a.workload == "vstream" else
                    ("VideoDepthAnything(%s).infer_video_depth on a %d-frame 518x518 u8 clip = %d windows of 32 (host frames in, "
                     "host depth out: H2D, pre-processing, device stitcher and D2H inside the timed region); windows sharded over the GPUs"
                     % (enc, frames_per_step, len(util.window_table(frames_per_step)))),
@@ -183,7 +190,7 @@ def main():
     # ---------------- roofline of the dominant kernel (encoder linear GEMMs)
     if ev:
         C = vdn.modules.ENCODERS[enc]["dim"]
-        per_launch = a.batch if a.workload == "stream" else 32  # frames one encoder launch covers
+        per_launch = a.batch if a.workload == "stream" else (1 if a.workload == "vstream" else 32)  # frames per encoder launch
         M = per_launch * (37 * 37 + 1)
         ms = [s.elapsed_time(e) for (tag, s, e) in ev if tag == "enc_linear"]
         if ms:

@@ -683,3 +683,25 @@ def test_device_stitcher_singular_fit_is_identity(rt):
     rt.stitch_fit(pred, pred.clone(), coef)
     # a00*a11 - a01^2 = (9n)(n) - (3n)^2 = 0
     assert coef.cpu().tolist() == [1.0, 0.0]
+
+
+@pytest.mark.parametrize("T,HW,c", [(1, 37, 256), (7, 50, 1024), (32, 133, 256), (32, 20, 64), (9, 31, 384), (32, 40, 192)])
+def test_temporal_attention_last_frame_over_projected_cache(rt3, T, HW, c):
+    """vdn_temporal_attn_last: W(x + pe[t]) = Wx + W pe[t] — cached projections without the position term plus
+    [T, c] position tables must equal attention of the newest frame over re-projected (state + pe) inputs
+    (motion_module.py:255-277), 8 heads."""
+    g = torch.Generator().manual_seed(500 + T + c)
+    states = torch.randn(T, HW, c, generator=g)
+    pe = torch.randn(T, c, generator=g) * 0.5
+    wq, wk, wv = (torch.randn(c, c, generator=g) / math.sqrt(c) for _ in range(3))
+    xin = (states + pe[:, None, :]).double()
+    q = (xin[-1] @ wq.double().t()).reshape(HW, 8, c // 8)
+    k = (xin @ wk.double().t()).reshape(T, HW, 8, c // 8)
+    v = (xin @ wv.double().t()).reshape(T, HW, 8, c // 8)
+    att = torch.softmax(torch.einsum("phd,tphd->pht", q, k) * (c // 8) ** -0.5, dim=-1)
+    ref = torch.einsum("pht,tphd->phd", att, v).reshape(HW, c).float()
+    entries = [torch.cat([st.double() @ w.double().t() for w in (wq, wk, wv)], dim=1).float().to(DEV).contiguous() for st in states]
+    tabs = [(pe.double() @ w.double().t()).float().to(DEV).contiguous() for w in (wq, wk, wv)]
+    out = rt3.hbuf(f"t_tal_{T}_{c}", (HW, c))
+    rt3.temporal_attn_last(entries, tabs[0], tabs[1], tabs[2], out, HW, c, (c // 8) ** -0.5)
+    close(out.float(), ref, 5e-6)

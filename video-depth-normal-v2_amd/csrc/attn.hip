@@ -491,6 +491,76 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// temporal_last_kernel — streaming mode (video_depth_stream.py:133-158, motion_module.py:255-277) with a
+// PROJECTED key/value cache: every cached frame keeps its q|k|v projection WITHOUT the
+// frame-position term (f32 [HW, 3c], the position is not known when the frame is cached: the window slides);
+// by linearity  W (x + pe[t]) = W x + W pe[t],  so the position enters as three small tables
+// (pe W_q^T, pe W_k^T, pe W_v^T: f32 [T, c] each) added on load. Only the NEWEST frame queries (the reference
+// computes all T and keeps the last). One wave per pixel: lane owns c/64 consecutive channels, a head
+// (c/8 channels) is 8 consecutive lanes; scores are reduced inside the 8-lane group, softmax over the
+// <= 32 frames in registers, output written as operand planes for the out-projection GEMM. HBM-bound:
+// T x 2c f32 per pixel are read once.
+template <int DT, int CPL /*channels per lane: c / 64*/>
+__global__ __launch_bounds__(256) void temporal_last_kernel(const float* const* __restrict__ entries, int T, int HW, int c,
+                                                            const float* __restrict__ peq, const float* __restrict__ pek,
+                                                            const float* __restrict__ pev, float scale,
+                                                            typename Half<DT>::T* __restrict__ out,
+                                                            typename Half<DT>::T* __restrict__ out_lo) {
+  using Th = typename Half<DT>::T;
+  const int lane = threadIdx.x & 63;
+  const int px = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (px >= HW) return;
+  const int ch = lane * CPL;
+  const size_t row = (size_t)px * 3 * c;
+  float q[CPL];
+  {
+    const float* qn = entries[T - 1] + row + ch;  // the newest frame is the query, at position T-1
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) q[e] = (qn[e] + peq[(size_t)(T - 1) * c + ch + e]) * scale;
+  }
+  float sc[32];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 32; ++t) {
+    sc[t] = -INFINITY;
+    if (t < T) {
+      const float* kt = entries[t] + row + c + ch;
+      const float* pk = pek + (size_t)t * c + ch;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) d = fmaf(q[e], kt[e] + pk[e], d);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      d += __shfl_xor(d, 4);
+      sc[t] = d;
+      mx = fmaxf(mx, d);
+    }
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < 32; ++t) {
+    sc[t] = t < T ? __expf(sc[t] - mx) : 0.f;
+    den += sc[t];
+  }
+  const float inv = 1.0f / den;
+  float o[CPL];
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 32; ++t) {
+    if (t < T) {
+      const float* vt = entries[t] + row + 2 * c + ch;
+      const float* pv = pev + (size_t)t * c + ch;
+      const float p = sc[t] * inv;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) o[e] = fmaf(p, vt[e] + pv[e], o[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) store_half(out, out_lo, (size_t)px * c + ch + e, o[e]);
+}
+
 template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
                  void* outl, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
@@ -561,4 +631,33 @@ extern "C" int vdn_temporal_attn(int dt, const void* qkv, void* out, const void*
   if (dt == VDN_F16) return temporal_launch<VDN_F16>(qkv, out, qkv_lo, out_lo, nseq, T, D, c, heads, sl2, s);
   if (dt == VDN_BF16) return temporal_launch<VDN_BF16>(qkv, out, qkv_lo, out_lo, nseq, T, D, c, heads, sl2, s);
   return VDN_EUNSUPPORTED;
+}
+
+extern "C" int vdn_temporal_attn_last(int dt, const void* const* entries, int T, int HW, int c, const float* pe_q,
+                                      const float* pe_k, const float* pe_v, float scale, void* out, void* out_lo,
+                                      vdn_stream stream) {
+  if (!entries || !pe_q || !pe_k || !pe_v || !out || T < 1 || T > 32 || HW <= 0) return VDN_EINVAL;
+  if (c <= 0 || (c & 63) || c > 1024) return VDN_EUNSUPPORTED;  // 8 heads of c/8 = 8 lanes x c/64 channels
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((HW + 3) / 4), block(256);
+#define VDN_TL(DT_, CPL_)                                                                                                  \
+  hipLaunchKernelGGL((temporal_last_kernel<DT_, CPL_>), grid, block, 0, s, (const float* const*)entries, T, HW, c, pe_q, pe_k, \
+                     pe_v, scale, (typename Half<DT_>::T*)out, (typename Half<DT_>::T*)out_lo)
+#define VDN_TL_C(DT_)                                  \
+  switch (c) {                                         \
+    case 64: VDN_TL(DT_, 1); break;                    \
+    case 128: VDN_TL(DT_, 2); break;                   \
+    case 192: VDN_TL(DT_, 3); break;                   \
+    case 256: VDN_TL(DT_, 4); break;                   \
+    case 384: VDN_TL(DT_, 6); break;                   \
+    case 512: VDN_TL(DT_, 8); break;                   \
+    case 768: VDN_TL(DT_, 12); break;                  \
+    case 1024: VDN_TL(DT_, 16); break;                 \
+    default: return VDN_EUNSUPPORTED;                  \
+  }
+  if (dt == VDN_F16) { VDN_TL_C(VDN_F16) } else if (dt == VDN_BF16) { VDN_TL_C(VDN_BF16) } else return VDN_EUNSUPPORTED;
+#undef VDN_TL_C
+#undef VDN_TL
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
 }

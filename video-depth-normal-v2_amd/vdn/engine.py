@@ -125,9 +125,14 @@ class TemporalEngine:
         for i in range(2):
             a = blk.attention_blocks[i]
             wqkv, _ = pack.cat_proj([a.to_q.weight, a.to_k.weight, a.to_v.weight], [None, None, None], [0, 0, 0], h)
+            pe64 = a.pos_encoder.pe.detach().double().reshape(-1, c)
             self.att.append(dict(
                 nw=pack.f32(blk.norms[i].weight), nb=pack.f32(blk.norms[i].bias), wqkv=wqkv,
                 pe=pack.f32(a.pos_encoder.pe).reshape(-1, c),
+                # streaming mode: W (x + pe[t]) = W x + W pe[t] -> the position term of each projection as a [T, c] table
+                pe_q=(pe64 @ a.to_q.weight.detach().double().t()).float().contiguous(),
+                pe_k=(pe64 @ a.to_k.weight.detach().double().t()).float().contiguous(),
+                pe_v=(pe64 @ a.to_v.weight.detach().double().t()).float().contiguous(),
                 wo=pack.linear(a.to_out[0].weight, h), bo=pack.f32(a.to_out[0].bias)))
         self.fnw, self.fnb = pack.f32(blk.ff_norm.weight), pack.f32(blk.ff_norm.bias)
         self.wg, self.bg = pack.geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, h)
@@ -174,31 +179,27 @@ class TemporalEngine:
         return self.out(self.core(self.gn(x, B * T, HW), B, T, HW), x, B * T * HW)
 
     def run_stream(self, x, HW: int, cached, new_entries: list):
-        """Streaming step (video_depth_stream.py:76-160, motion_module.py:255-277): x is ONE frame
-        [HW, c]. `cached` is None for the first frame (attention over the frame itself) or a list, per
-        attention block, of the 31 cached LayerNorm outputs (f32 [HW, c], oldest first); the new frame's
-        states are appended to `new_entries`. Keys/values are re-projected from the cached states
-        with the position table of the current window, exactly as the reference does."""
-        from .runtime import HL
+        """Streaming step (video_depth_stream.py:76-160, motion_module.py:255-277): x is ONE frame [HW, c].
+        `cached` is None for the first frame (attention over the frame itself) or a list, per attention block,
+        of the 31 cached entries (oldest first); the new frame's entries are appended to `new_entries`.
+        An entry is the frame's q|k|v PROJECTION without the position term (f32 [HW, 3c]): the
+        reference caches the LayerNorm output and re-projects all 32 frames with the sliding window's positions
+        every step; here each frame is projected once and the positions enter as [T, c] tables inside
+        `vdn_temporal_attn_last` (W(x + pe) = Wx + W pe), which also computes the newest frame's query only."""
         rt, c = self.rt, self.c
         g = self.gn(x, 1, HW)
         hs = rt.fbuf("ts_h", (HW, c))
         rt.gemm(g, self.w_in, HW, c, c, bias=self.b_in, out=hs)
-        nf = rt.fbuf("ts_nf", (HW, c))
-        T = 1 if cached is None else len(cached[0]) + 1
-        seqh = rt.hbuf("ts_seq", (T * HW, c))
-        qkv = rt.hbuf("ts_qkv", (T * HW, 3 * c))
-        a = rt.hbuf("ts_a", (T * HW, c))
+        nh = rt.hbuf("ts_nh", (HW, c))
+        a = rt.hbuf("ts_a", (HW, c))
         for j, at in enumerate(self.att):
-            rt.layernorm(hs, HW, c, at["nw"], at["nb"], 1e-5, out_f=nf)
-            entry = nf.clone()
+            rt.layernorm(hs, HW, c, at["nw"], at["nb"], 1e-5, out_h=nh)
+            entry = torch.empty((HW, 3 * c), dtype=torch.float32, device=rt.device)
+            rt.gemm(nh, at["wqkv"], HW, 3 * c, c, out=entry)
             new_entries.append(entry)
-            seq = entry if cached is None else torch.cat(list(cached[j]) + [entry], dim=0)
-            rt.addtab_cast(seq, at["pe"], HW, T, seqh, T * HW, c)
-            rt.gemm(seqh, at["wqkv"], T * HW, 3 * c, c, out=qkv)
-            rt.temporal_attn(qkv, a, 1, T, HW, c, 8, (c // 8) ** -0.5)
-            last = HL(a.hi[(T - 1) * HW:], None if a.lo is None else a.lo[(T - 1) * HW:])
-            rt.gemm(last, at["wo"], HW, c, c, bias=at["bo"], res1=hs, out=hs)
+            window = [entry] if cached is None else list(cached[j]) + [entry]
+            rt.temporal_attn_last(window, at["pe_q"], at["pe_k"], at["pe_v"], a, HW, c, (c // 8) ** -0.5)
+            rt.gemm(a, at["wo"], HW, c, c, bias=at["bo"], res1=hs, out=hs)
         n = rt.hbuf("ts_n", (HW, c))
         rt.layernorm(hs, HW, c, self.fnw, self.fnb, 1e-5, out_h=n)
         gg = rt.hbuf("ts_gg", (HW, 4 * c))
