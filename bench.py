@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=7)
-    ap.add_argument("--workload", choices=["stream", "clip", "video", "vstream"], default="stream")
+    ap.add_argument("--workload", choices=["stream", "clip", "video", "vstream", "refine5"], default="stream")
     ap.add_argument("--video-frames", type=int, default=256, help="video workload: clip length (BASELINE configs[3]: 256)")
     ap.add_argument("--batch", type=int, default=8, help="streams per GPU (stream) / frames per window (clip: 32)")
     ap.add_argument("--encoder", default="vitl")
@@ -90,6 +90,10 @@ def main():
     elif a.workload == "clip":
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = 32
+    elif a.workload == "refine5":  # v5 depth refiner (BASELINE configs[4]) on a [1, 32, 1024, 1024] raw depth clip
+        from vdn.video_depth_model_v5 import VideoDepthAnything as RefinerV5
+        model = RefinerV5(**cfg)
+        frames_per_step = 32
     elif a.workload == "vstream":  # latency mode: one frame per step against the 31-frame projected K/V cache
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = 1
@@ -111,6 +115,8 @@ def main():
         from vdn.dist import infer_video_depth_sharded
         video = np.ascontiguousarray(np.tile(fr, ((frames_per_step + 7) // 8, 1, 1, 1))[:frames_per_step])
     x = torch.from_numpy(synth.normalize_frames(fr)).to(dev)
+    if a.workload == "refine5":
+        xd = torch.from_numpy(synth.depth_clip(1234 + rank, 4, 1024, 1024)).to(dev).repeat(8, 1, 1)[None].contiguous()
     if x.shape[0] < frames_per_step:
         x = x.repeat((frames_per_step + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:frames_per_step]
     if a.workload == "clip":
@@ -124,6 +130,8 @@ def main():
             return model.infer_video_depth(video, 24, input_size=518)[0]
         if a.workload == "vstream":
             return model.stream_step(x[:1][None])
+        if a.workload == "refine5":
+            return model.forward(xd)
         return model.forward(x)
 
     def sync_all():
@@ -170,7 +178,8 @@ def main():
         os.environ["VDN_STREAMS"] = str(lanes)
 
     out = {
-        "metric": "depth frames/sec at 518x518, ViT-L" if enc == "vitl" else f"depth frames/sec at 518x518, {enc}",
+        "metric": ("refined depth frames/sec at 1024x1024 (v5 refiner), " + enc) if a.workload == "refine5" else
+                  ("depth frames/sec at 518x518, ViT-L" if enc == "vitl" else f"depth frames/sec at 518x518, {enc}"),
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
         "scaling": "strong" if a.workload == "video" else "weak", "vs_baseline": None,
@@ -178,6 +187,8 @@ def main():
         "config": {"workload": ("DepthAnythingV2(%s) batch=%d 518x518 streams/GPU, memory bank full (S=6); replicas per GPU"
                                 % (enc, a.batch)) if a.workload == "stream" else
                    ("VideoDepthAnything(%s) one 32-frame 518x518 window per step; one window per GPU" % enc) if a.workload == "clip" else
+                   ("video_depth_model_v5.VideoDepthAnything(%s).forward on a [1,32,1024,1024] raw depth clip (median scale, "
+                    "224x224 network, shift + residual); the metric counts refined 1024x1024 frames" % enc) if a.workload == "refine5" else
                    ("VideoDepthAnything(%s).stream_step: one 518x518 frame per step against 31 cached frames (projected K/V cache)" % enc)
                    if a.workload == "vstream" else
                    ("VideoDepthAnything(%s).infer_video_depth on a %d-frame 518x518 u8 clip = %d windows of 32 (host frames in, "
@@ -191,7 +202,7 @@ def main():
     if ev:
         C = vdn.modules.ENCODERS[enc]["dim"]
         per_launch = a.batch if a.workload == "stream" else (1 if a.workload == "vstream" else 32)  # frames per encoder launch
-        M = per_launch * (37 * 37 + 1)
+        M = per_launch * ((16 * 16 + 1) if a.workload == "refine5" else (37 * 37 + 1))
         ms = [s.elapsed_time(e) for (tag, s, e) in ev if tag == "enc_linear"]
         if ms:
             avg_ms = sum(ms) / len(ms)

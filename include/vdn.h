@@ -225,6 +225,23 @@ int vdn_stitch_fit(const float* pred, const float* target, size_t n, void* works
 int vdn_stitch_apply(const float* window, const float* coef, float* out_tail, float* out_new, float* ref1, size_t hw,
                      int T, int align_len, int overlap, int ref_frame, vdn_stream stream);
 
+/* Depth-refiner wrappers v4 / v5 (models/video_depth_model_v5.py:63-87,160-192, models/video_depth_model_v4.py:117-148,
+ * utils/normal_utils.py:4-51). f32 throughout, frames are [frames, n = H*W] row-major.
+ * vdn_frame_median  — median[f] = torch.quantile(x[f], 0.5) (linear interpolation), exact radix select;
+ *                     workspace = vdn_frame_median_workspace_bytes(frames).
+ * vdn_refine_scale  — out = x / max_depth * s_f, s_f = exp(tanh(w * median[f] / max_depth + b) * max_log_scale)
+ *                     (GlobalScaleHead: quantile pool -> 1x1 conv -> TanhToExp); scale_out[f] = s_f (may be NULL).
+ * vdn_refine_pack   — encoder input [frames,3,H,W] = (d, nx, ny); normals != 0: Sobel/8 on a reflect-padded map,
+ *                     n = (-Ix,-Iy,1)/sqrt(Ix^2+Iy^2+1+1e-8); normals == 0: d broadcast to 3 channels.
+ * vdn_refine_finish — out = (scaled + (w * depth + b)) * max_depth (residual != 0) or depth * max_depth.           */
+size_t vdn_frame_median_workspace_bytes(int frames);
+int vdn_frame_median(const float* x, int frames, size_t n, float* median, void* workspace, vdn_stream stream);
+int vdn_refine_scale(const float* x, const float* median, int frames, size_t n, float w, float b, float max_log_scale,
+                     float max_depth, float* out, float* scale_out, vdn_stream stream);
+int vdn_refine_pack(const float* d, float* out, int frames, int H, int W, int normals, vdn_stream stream);
+int vdn_refine_finish(const float* scaled, const float* depth, float w, float b, float max_depth, int residual, float* out,
+                      size_t n, vdn_stream stream);
+
 /* misc */
 int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);
 size_t vdn_sizeof_gemm_desc(void);      /* layout probes for FFI bindings */

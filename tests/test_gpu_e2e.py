@@ -214,3 +214,26 @@ def test_streaming_mode_against_reference_fixture():
                 ref = O.video_depth_stream_step(sd, x[t][None, None], st, "vits", pre_relu=True)
             assert rel_l2(torch.relu(pre), torch.relu(ref)) < TOL
     assert len(model._stream["cache"]) == 42
+
+
+@pytest.mark.parametrize("version,name", [(5, "R5_vits"), (4, "R4_vits")])
+def test_depth_refiner_v4_v5_against_reference_fixture(version, name):
+    """the v4 / v5 wrappers (median radix select, scale, Sobel normals, temporal network, shift +
+    residual) against the fixture written by the imported reference model; tolerance 1e-3 on the refined depth."""
+    import importlib
+    import vdn
+    from vdn import synth
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    v, S, H, W, seed = [int(t) for t in g["meta"]]
+    cls = importlib.import_module(f"vdn.video_depth_model_v{version}").VideoDepthAnything
+    m = cls(**vdn.MODEL_CONFIGS["vits"])
+    m.load_state_dict(synth_sd(f"R{version}", "vits"), strict=True)
+    m = m.to("cuda").eval()
+    x = torch.from_numpy(synth.depth_clip(seed, S, H, W))[None]
+    out = m.forward(x.cuda())[0].cpu()
+    e = rel_l2(out, g["out"])
+    print(f"[{name}] refined depth vs reference fixture {e:.2e}")
+    assert torch.isfinite(out).all() and e < TOL
+    # two clips in one batch are independent
+    both = m.forward(torch.cat([x, x * 0.5 + 100.0]).cuda()).cpu()
+    assert rel_l2(both[0], g["out"]) < TOL

@@ -705,3 +705,45 @@ def test_temporal_attention_last_frame_over_projected_cache(rt3, T, HW, c):
     out = rt3.hbuf(f"t_tal_{T}_{c}", (HW, c))
     rt3.temporal_attn_last(entries, tabs[0], tabs[1], tabs[2], out, HW, c, (c // 8) ** -0.5)
     close(out.float(), ref, 5e-6)
+
+
+@pytest.mark.parametrize("F_,n", [(1, 1), (3, 2), (2, 1001), (5, 4096), (2, 90 * 121), (1, 300001)])
+def test_frame_median_matches_torch_quantile(rt, F_, n):
+    """vdn_frame_median = torch.quantile(x, 0.5) (linear interpolation): odd / even counts, negatives, duplicates."""
+    g = torch.Generator().manual_seed(600 + n)
+    x = torch.randn(F_, n, generator=g) * 3.0
+    x[0, : n // 3] = x[0, 0]                       # a run of duplicates straddling the median region
+    if F_ > 1:
+        x[1] = torch.round(x[1])                   # heavy ties
+    med = torch.empty(F_, device=DEV)
+    rt.frame_median(x.to(DEV).contiguous(), med)
+    ref = torch.quantile(x, 0.5, dim=-1)
+    assert torch.equal(med.cpu(), ref), (med.cpu() - ref).abs().max()
+
+
+def test_refiner_scale_pack_finish_kernels(rt):
+    """vdn_refine_scale / _pack / _finish against the oracle's torch statement (utils/normal_utils.py:4-51)."""
+    from oracle import ref_cpu as O
+    F_, H, W = 3, 19, 23
+    g = torch.Generator().manual_seed(610)
+    x = torch.rand(F_, H, W, generator=g) * 60000.0 + 100.0
+    med = torch.quantile(x.reshape(F_, -1), 0.5, dim=-1)
+    w, b = 0.7, -0.2
+    s_ref = torch.exp(torch.tanh(med / 65535.0 * w + b))
+    scaled, sc = torch.empty(F_, H, W, device=DEV), torch.empty(F_, device=DEV)
+    rt.refine_scale(x.to(DEV), med.to(DEV), w, b, 1.0, 65535.0, scaled, sc)
+    close(sc.cpu(), s_ref, 1e-6)
+    close(scaled.cpu(), x / 65535.0 * s_ref.reshape(F_, 1, 1), 1e-6)
+    d = scaled.cpu()
+    packed = torch.empty(F_, 3, H, W, device=DEV)
+    rt.refine_pack(scaled, packed, normals=True)
+    ref = torch.cat([d[:, None], O.sobel_normals(d[:, None])[:, :2]], dim=1)
+    close(packed.cpu(), ref, 2e-6)
+    rt.refine_pack(scaled, packed, normals=False)
+    assert torch.equal(packed.cpu(), d[:, None].expand(-1, 3, -1, -1))
+    depth = torch.rand(F_, H, W, generator=g)
+    out = torch.empty(F_, H, W, device=DEV)
+    rt.refine_finish(scaled, depth.to(DEV), 1.3, 0.05, 65535.0, True, out)
+    close(out.cpu(), (d + (depth * 1.3 + 0.05)) * 65535.0, 1e-6)
+    rt.refine_finish(None, depth.to(DEV), 1.3, 0.05, 65535.0, False, out)
+    close(out.cpu(), depth * 65535.0, 1e-6)

@@ -102,6 +102,19 @@ def test_state_dict_schema_matches_reference(which, enc):
     m.load_state_dict(sd, strict=True)
 
 
+@pytest.mark.parametrize("version", [4, 5])
+def test_refiner_state_dict_schema_matches_reference(version):
+    """v4 / v5 depth-refiner wrappers: same keys and shapes as models/video_depth_model_v{4,5}.VideoDepthAnything."""
+    import importlib
+    import vdn
+    cls = importlib.import_module(f"vdn.video_depth_model_v{version}").VideoDepthAnything
+    m = cls(**vdn.MODEL_CONFIGS["vits"])
+    sch = schema(f"R{version}", "vits")
+    assert {k: tuple(v.shape) for k, v in m.named_parameters()} == {k: tuple(s) for k, s in sch["params"]}
+    assert {k: tuple(v.shape) for k, v in m.named_buffers()} == {k: tuple(s) for k, s in sch["buffers"]}
+    m.load_state_dict(m.state_dict(), strict=True)
+
+
 def test_product_refuses_cpu():
     import vdn
     m = vdn.DepthAnythingV2(**vdn.MODEL_CONFIGS["vits"])

@@ -197,6 +197,41 @@ def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str):
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
+def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str):
+    """models/video_depth_model_v{4,5}.VideoDepthAnything on a synthetic depth clip."""
+    import importlib
+    from vdn import synth
+    from oracle import ref_cpu as O
+    # models/__init__.py pulls in the HuggingFace encoder wrappers (transformers -> torchvision probing), which this
+    # path never uses: load the one module file directly instead of through the package
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(f"ref_video_depth_model_v{version}",
+                                                  os.path.join(REF, "models", f"video_depth_model_v{version}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = O.MODEL_CONFIGS[enc]
+    torch.manual_seed(0)
+    model = mod.VideoDepthAnything(**cfg).eval()
+    sd, shapes = load_synth(model)
+    with open(os.path.join(GOLD, f"schema_R{version}_{enc}.json"), "w") as f:
+        json.dump({"params": [[k, list(s)] for k, s in shapes],
+                   "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
+    x = torch.from_numpy(synth.depth_clip(SEED, S, H, W))[None]
+    t0 = time.time()
+    with torch.no_grad():
+        ref = model(x)
+    tr = {}
+    with torch.no_grad():
+        mine = O.depth_refiner_forward(sd, x, enc, version=version, trace=tr)
+    e = relerr(mine, ref)
+    print(f"[R{version} {name}] S={S} {H}x{W} ref {time.time() - t0:.1f}s out mean {ref.mean():.1f} std {ref.std():.1f} "
+          f"scale {tr['scale'].numpy().round(4)} net_depth mean {tr['net_depth'].mean():.4f} | oracle rel err {e:.2e}")
+    assert e <= 1e-5
+    out = {"meta": np.array([version, S, H, W, SEED]), "out": ref[0].numpy(), "median": tr["median"].numpy(),
+           "scale": tr["scale"].numpy(), "net_depth": tr["net_depth"][0].numpy()}
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+
+
 def gen_stream(enc: str, H: int, W: int, n: int, keep: list, name: str):
     """video_depth_stream.infer_video_depth_one semantics: feed pre-processed frames through
     forward_features/forward_depth with the reference's own cache bookkeeping (video_depth_stream.py:76-160)."""
@@ -343,6 +378,8 @@ JOBS = {
     "S_vits_266": lambda: gen_stream("vits", 266, 266, 14, [0, 1, 11, 13], "S_vits_266"),
     "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 2, [0, 1], 4, "A_vitl_518"),
     "B_vitl_518": lambda: gen_B("vitl", 518, 518, 4, [0, 3], 4, "B_vitl_518"),
+    "R5_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5_vits"),
+    "R4_vits": lambda: gen_refiner(4, "vits", 3, 126, 168, "R4_vits"),
 }
 
 if __name__ == "__main__":

@@ -76,6 +76,11 @@ EXPORTS = {
     "vdn_addtab_cast": (C.c_int, [C.c_int, fp, fp, C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]),
     "vdn_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_size_t, vp]),
     "vdn_temporal_attn_last": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_float, vp, vp, vp]),
+    "vdn_frame_median_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "vdn_frame_median": (C.c_int, [fp, C.c_int, C.c_size_t, fp, vp, vp]),
+    "vdn_refine_scale": (C.c_int, [fp, fp, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, vp]),
+    "vdn_refine_pack": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_refine_finish": (C.c_int, [fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, fp, C.c_size_t, vp]),
     "vdn_stitch_workspace_bytes": (C.c_size_t, []),
     "vdn_stitch_fit": (C.c_int, [fp, fp, C.c_size_t, vp, fp, vp]),
     "vdn_stitch_apply": (C.c_int, [fp, fp, fp, fp, fp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -275,6 +275,25 @@ class Runtime:
         self._launch(abi.lib.vdn_stitch_apply, window.data_ptr(), coef.data_ptr(), out_tail.data_ptr(), out_new.data_ptr(),
                      ref1.data_ptr(), hw, T, align_len, overlap, ref_frame)
 
+    def frame_median(self, x: torch.Tensor, median: torch.Tensor):
+        """median[f] = torch.quantile(x[f], 0.5) for f32 x [F, ...] (exact radix select on the device)."""
+        F = x.shape[0]
+        ws = self.buf("median_ws", ((abi.lib.vdn_frame_median_workspace_bytes(F) + 7) // 8,), torch.int64)
+        assert x.is_contiguous() and x.dtype == torch.float32 and median.numel() == F
+        self._launch(abi.lib.vdn_frame_median, x.data_ptr(), F, x[0].numel(), median.data_ptr(), ws.data_ptr())
+
+    def refine_scale(self, x, median, w: float, b: float, max_log_scale: float, max_depth: float, out, scale_out=None):
+        self._launch(abi.lib.vdn_refine_scale, x.data_ptr(), median.data_ptr(), x.shape[0], x[0].numel(), w, b, max_log_scale,
+                     max_depth, out.data_ptr(), self._p(scale_out))
+
+    def refine_pack(self, d, out, normals: bool = True):
+        F, H, W = d.shape
+        self._launch(abi.lib.vdn_refine_pack, d.data_ptr(), out.data_ptr(), F, H, W, int(normals))
+
+    def refine_finish(self, scaled, depth, w: float, b: float, max_depth: float, residual: bool, out):
+        self._launch(abi.lib.vdn_refine_finish, self._p(scaled), depth.data_ptr(), w, b, max_depth, int(residual), out.data_ptr(),
+                     depth.numel())
+
     def patchify(self, img, rows, B: int, H: int, W: int, ldk: int):
         rows, rl = _hl(rows)
         self._launch(abi.lib.vdn_patchify, self.dt, img.data_ptr(), rows.data_ptr(), rl, B, H, W, ldk)

@@ -76,6 +76,19 @@ IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
 IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32)
 
 
+def depth_clip(seed: int, n: int, h: int, w: int, max_depth: float = 65535.0) -> np.ndarray:
+    """Synthetic raw depth clip f32 [n,h,w] in (0, max_depth): a smooth tilted surface with a bump that moves
+    from frame to frame plus counter-hash noise (inputs of the v4 / v5 depth refiners)."""
+    yy, xx = np.meshgrid(np.linspace(0.0, 1.0, h, dtype=np.float32), np.linspace(0.0, 1.0, w, dtype=np.float32), indexing="ij")
+    out = np.empty((n, h, w), dtype=np.float32)
+    for t in range(n):
+        cx, cy = 0.3 + 0.1 * t, 0.6 - 0.05 * t
+        base = 0.25 + 0.3 * xx + 0.15 * yy + 0.2 * np.exp(-(((xx - cx) ** 2 + (yy - cy) ** 2) / 0.02)).astype(np.float32)
+        noise = normal(seed, f"depth_clip.{t}", (h, w)).astype(np.float32)
+        out[t] = np.clip(base * (1.0 + 0.05 * t) + 0.01 * noise, 0.01, 0.99) * max_depth
+    return out
+
+
 def normalize_frames(frames: np.ndarray) -> np.ndarray:
     """u8[n,h,w,3] RGB -> f32[n,3,h,w], (x/255 - mean)/std  (depth_anything_v2.py:78, transform.py:133-148)."""
     x = frames.astype(np.float32) / 255.0
@@ -118,7 +131,7 @@ def _scale_rules(key: str, shape: Tuple[int, ...], z):
         return 1.0 + 0.1 * z if leaf == "weight" else 0.05 * z
     if leaf == "bias":
         if key.endswith("output_conv2.2.bias"):
-            return (1.5 if key.startswith("head.") else 0.5) + 0.0 * z
+            return (1.5 if key.startswith(("head.", "temporal_head.")) else 0.5) + 0.0 * z
         if key.endswith("output_conv2.0.bias"):
             return 0.1 + 0.05 * z
         return 0.05 * z
