@@ -90,10 +90,10 @@ def main():
     elif a.workload == "clip":
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = 32
-    elif a.workload == "refine5":  # v5 depth refiner (BASELINE configs[4]) on a [1, 32, 1024, 1024] raw depth clip
+    elif a.workload == "refine5":  # v5 depth refiner (BASELINE configs[4]): num_frames 64, [1, 64, 1024, 1024] raw depth clip
         from vdn.video_depth_model_v5 import VideoDepthAnything as RefinerV5
-        model = RefinerV5(**cfg)
-        frames_per_step = 32
+        model = RefinerV5(num_frames=64, **cfg)
+        frames_per_step = 64
     elif a.workload == "vstream":  # latency mode: one frame per step against the 31-frame projected K/V cache
         model = vdn.VideoDepthAnything(**cfg)
         frames_per_step = 1
@@ -116,7 +116,7 @@ def main():
         video = np.ascontiguousarray(np.tile(fr, ((frames_per_step + 7) // 8, 1, 1, 1))[:frames_per_step])
     x = torch.from_numpy(synth.normalize_frames(fr)).to(dev)
     if a.workload == "refine5":
-        xd = torch.from_numpy(synth.depth_clip(1234 + rank, 4, 1024, 1024)).to(dev).repeat(8, 1, 1)[None].contiguous()
+        xd = torch.from_numpy(synth.depth_clip(1234 + rank, 4, 1024, 1024)).to(dev).repeat(16, 1, 1)[None].contiguous()
     if x.shape[0] < frames_per_step:
         x = x.repeat((frames_per_step + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:frames_per_step]
     if a.workload == "clip":
@@ -187,7 +187,7 @@ def main():
         "config": {"workload": ("DepthAnythingV2(%s) batch=%d 518x518 streams/GPU, memory bank full (S=6); replicas per GPU"
                                 % (enc, a.batch)) if a.workload == "stream" else
                    ("VideoDepthAnything(%s) one 32-frame 518x518 window per step; one window per GPU" % enc) if a.workload == "clip" else
-                   ("video_depth_model_v5.VideoDepthAnything(%s).forward on a [1,32,1024,1024] raw depth clip (median scale, "
+                   ("video_depth_model_v5.VideoDepthAnything(%s, num_frames=64).forward on a [1,64,1024,1024] raw depth clip (median scale, "
                     "224x224 network, shift + residual); the metric counts refined 1024x1024 frames" % enc) if a.workload == "refine5" else
                    ("VideoDepthAnything(%s).stream_step: one 518x518 frame per step against 31 cached frames (projected K/V cache)" % enc)
                    if a.workload == "vstream" else
@@ -201,7 +201,7 @@ def main():
     # ---------------- roofline of the dominant kernel (encoder linear GEMMs)
     if ev:
         C = vdn.modules.ENCODERS[enc]["dim"]
-        per_launch = a.batch if a.workload == "stream" else (1 if a.workload == "vstream" else 32)  # frames per encoder launch
+        per_launch = a.batch if a.workload == "stream" else (1 if a.workload == "vstream" else (64 if a.workload == "refine5" else 32))  # frames per encoder launch
         M = per_launch * ((16 * 16 + 1) if a.workload == "refine5" else (37 * 37 + 1))
         ms = [s.elapsed_time(e) for (tag, s, e) in ev if tag == "enc_linear"]
         if ms:

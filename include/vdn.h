@@ -141,7 +141,7 @@ int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* o
                    const void* K_lo, const void* Vt_lo, void* out_lo, int B, int H, int nq, int nq_pad, int nk,
                    int nk_pad, float scale, vdn_stream stream);
 
-/* Temporal attention over <=32 frames per (pixel, head): qkv half [(b f), D, 3c] packed
+/* Temporal attention over <=64 frames per (pixel, head) (32 in the 32-frame windows, 64 in the v5 refiner): qkv half [(b f), D, 3c] packed
  * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)
  * with the rearranges of motion_module.py:255,320.                                              */
 int vdn_temporal_attn(int dt, const void* qkv, void* out, const void* qkv_lo, void* out_lo, int Bv, int T, int D,

@@ -266,7 +266,8 @@ def test_flash_attention_online_max_rescale(rt):
     close(out, ref, 2e-3)
 
 
-@pytest.mark.parametrize("Bv,T,D,c", [(2, 32, 9, 64), (1, 7, 5, 192), (1, 32, 3, 1024), (2, 4, 6, 256), (1, 1, 4, 384)])
+@pytest.mark.parametrize("Bv,T,D,c", [(2, 32, 9, 64), (1, 7, 5, 192), (1, 32, 3, 1024), (2, 4, 6, 256), (1, 1, 4, 384),
+                                       (1, 64, 5, 256), (2, 45, 3, 1024), (1, 33, 4, 64)])
 def test_temporal_attention(rt, Bv, T, D, c):
     heads, dh = 8, c // 8
     qkv = h(rnd(Bv * T, D, 3 * c, seed=100))
@@ -501,6 +502,17 @@ def test_x3_flash_attention(rt3, nq, nk, gain):
     for _ in range(3):  # bitwise repeatable (race screen for the LDS ring / counted waits)
         rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
         assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
+
+
+@pytest.mark.parametrize("T", [32, 64, 50])
+def test_x3_temporal_attention_up_to_64_frames(rt3, T):
+    Bv, D, c = 1, 5, 192
+    qkv = rnd(Bv * T, D, 3 * c, seed=245)
+    x = qkv.reshape(Bv, T, D, 3, 8, c // 8).permute(3, 0, 2, 4, 1, 5).double()
+    ref = F.scaled_dot_product_attention(x[0], x[1], x[2]).permute(0, 3, 1, 2, 4).reshape(Bv * T, D, c).float()
+    out = rt3.hbuf(f"t3_o{T}", (Bv * T, D, c))
+    rt3.temporal_attn(rt3.to_half(qkv.to(DEV)), out, Bv, T, D, c, 8, (c // 8) ** -0.5)
+    close(out.float(), ref, 1e-5)
 
 
 def test_x3_temporal_norms_upsample_headout(rt3):

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int DT, bool SPLIT>
+template <int DT, bool SPLIT, int NB /*32-frame blocks: sequences of up to 32 NB frames*/>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<DT>::T* __restrict__ qkv,
                                                             typename Half<DT>::T* __restrict__ out,
                                                             const typename Half<DT>::T* __restrict__ qkv_lo,
@@ -381,110 +381,127 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<
   const size_t boff = ((size_t)b * Tn * D + d) * 3 * c + head * dh;
   const T* base = qkv + boff;
   const T* base_lo = SPLIT ? qkv_lo + boff : nullptr;
-
-  // ---- S^T = K Q^T
-  const int fq = r < Tn ? r : Tn - 1;
-  const int pk = perm23(r);
-  const int fk = pk < Tn ? pk : Tn - 1;
-  f32x16 s;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = 0.f;
-  const int nks = (dh + 15) >> 4;
-  for (int ks = 0; ks < nks; ++ks) {
-    const int e0 = 16 * ks + 8 * h;
-    V8 a, bq, al, bl;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a[j] = (T)0.f; bq[j] = (T)0.f; al[j] = (T)0.f; bl[j] = (T)0.f; }
-    if (e0 < dh) {
-      bq = *(const V8*)(base + fq * rs + e0);
-      a = *(const V8*)(base + fk * rs + c + e0);
-      if constexpr (SPLIT) {
-        bl = *(const V8*)(base_lo + fq * rs + e0);
-        al = *(const V8*)(base_lo + fk * rs + c + e0);
-      }
-    }
-    s = HT::mfma32(a, bq, s);
-    if constexpr (SPLIT) {
-      s = HT::mfma32(a, bl, s);
-      s = HT::mfma32(al, bq, s);
-    }
-  }
-  float mx = -1e30f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float v = s[i] * scale_log2;
-    v = (acc_key(i, h) < Tn) ? v : -INFINITY;
-    s[i] = v;
-    mx = fmaxf(mx, v);
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float ls = 0.f;
-  V8 pf[2], pl[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float pv = __builtin_amdgcn_exp2f(s[i] - mx);
-    ls += pv;
-    if constexpr (SPLIT) {
-      T a2, b2;
-      split_rtz(pv, a2, b2);
-      pf[i >> 3][i & 7] = a2;
-      pl[i >> 3][i & 7] = b2;
-    } else {
-      pf[i >> 3][i & 7] = (T)pv;
-    }
-  }
-  ls += __shfl_xor(ls, 32);
-  const float inv = 1.0f / ls;
-
-  // ---- O^T = V^T P^T, 32 output dims per pass; V^T fragments gathered element-wise (tiny op)
   const T* vb = base + 2 * c;
   const T* vb_lo = SPLIT ? base_lo + 2 * c : nullptr;
   const size_t ooff = ((size_t)b * Tn * D + d) * c + head * dh;
   T* ob = out + ooff;
   T* ob_lo = SPLIT ? out_lo + ooff : nullptr;
   const size_t os = (size_t)D * c;
+  const int nks = (dh + 15) >> 4;
   const int neb = (dh + 31) >> 5;
-  for (int eb = 0; eb < neb; ++eb) {
-    f32x16 o;
+  const int pk = perm23(r);
+
+  for (int qb = 0; qb < NB; ++qb) {  // 32 query frames at a time (the v5 refiner runs 64-frame clips)
+    if (qb * 32 >= Tn) break;
+    const int tq = qb * 32 + r;
+    const int fq = tq < Tn ? tq : Tn - 1;
+    // ---- S^T = K Q^T, one 32 x 32 tile per key block
+    f32x16 s[NB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = 0.f;
-    const int e = eb * 32 + r;
+    for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-      V8 a, al;
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      if (kb * 32 >= Tn) continue;
+      const int tk = kb * 32 + pk;
+      const int fk = tk < Tn ? tk : Tn - 1;
+      for (int ks = 0; ks < nks; ++ks) {
+        const int e0 = 16 * ks + 8 * h;
+        V8 a, bq, al, bl;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = 16 * sp + 8 * h + j;
-        const bool ok = key < Tn && e < dh;
-        a[j] = ok ? vb[key * rs + e] : (T)0.f;
-        if constexpr (SPLIT) al[j] = ok ? vb_lo[key * rs + e] : (T)0.f;
-      }
-      o = HT::mfma32(a, pf[sp], o);
-      if constexpr (SPLIT) {
-        o = HT::mfma32(a, pl[sp], o);
-        o = HT::mfma32(al, pf[sp], o);
+        for (int j = 0; j < 8; ++j) { a[j] = (T)0.f; bq[j] = (T)0.f; al[j] = (T)0.f; bl[j] = (T)0.f; }
+        if (e0 < dh) {
+          bq = *(const V8*)(base + fq * rs + e0);
+          a = *(const V8*)(base + fk * rs + c + e0);
+          if constexpr (SPLIT) {
+            bl = *(const V8*)(base_lo + fq * rs + e0);
+            al = *(const V8*)(base_lo + fk * rs + c + e0);
+          }
+        }
+        s[kb] = HT::mfma32(a, bq, s[kb]);
+        if constexpr (SPLIT) {
+          s[kb] = HT::mfma32(a, bl, s[kb]);
+          s[kb] = HT::mfma32(al, bq, s[kb]);
+        }
       }
     }
-    if (r < Tn) {
+    float mx = -1e30f;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int e0 = eb * 32 + 8 * g + 4 * h;
-        if (e0 < dh) {
-          typename HT::V4 v, vl;
+    for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float x = o[4 * g + q] * inv;
-            if constexpr (SPLIT) {
-              T a2, b2;
-              split_rtz(x, a2, b2);
-              v[q] = a2;
-              vl[q] = b2;
-            } else {
-              v[q] = (T)x;
-            }
+      for (int i = 0; i < 16; ++i) {
+        float v = s[kb][i] * scale_log2;
+        v = (kb * 32 + acc_key(i, h) < Tn) ? v : -INFINITY;
+        s[kb][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float ls = 0.f;
+    V8 pf[NB][2], pl[NB][2];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(s[kb][i] - mx);
+        ls += pv;
+        if constexpr (SPLIT) {
+          T a2, b2;
+          split_rtz(pv, a2, b2);
+          pf[kb][i >> 3][i & 7] = a2;
+          pl[kb][i >> 3][i & 7] = b2;
+        } else {
+          pf[kb][i >> 3][i & 7] = (T)pv;
+        }
+      }
+    ls += __shfl_xor(ls, 32);
+    const float inv = 1.0f / ls;
+
+    // ---- O^T = V^T P^T, 32 output dims per pass; V^T fragments gathered element-wise (tiny op)
+    for (int eb = 0; eb < neb; ++eb) {
+      f32x16 o;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = 0.f;
+      const int e = eb * 32 + r;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        if (kb * 32 >= Tn) continue;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          V8 a, al;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int key = kb * 32 + 16 * sp + 8 * h + j;
+            const bool ok = key < Tn && e < dh;
+            a[j] = ok ? vb[key * rs + e] : (T)0.f;
+            if constexpr (SPLIT) al[j] = ok ? vb_lo[key * rs + e] : (T)0.f;
           }
-          *(typename HT::V4*)(ob + r * os + e0) = v;
-          if constexpr (SPLIT) *(typename HT::V4*)(ob_lo + r * os + e0) = vl;
+          o = HT::mfma32(a, pf[kb][sp], o);
+          if constexpr (SPLIT) {
+            o = HT::mfma32(a, pl[kb][sp], o);
+            o = HT::mfma32(al, pf[kb][sp], o);
+          }
+        }
+      }
+      if (tq < Tn) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int e0 = eb * 32 + 8 * g + 4 * h;
+          if (e0 < dh) {
+            typename HT::V4 v, vl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x = o[4 * g + q] * inv;
+              if constexpr (SPLIT) {
+                T a2, b2;
+                split_rtz(x, a2, b2);
+                v[q] = a2;
+                vl[q] = b2;
+              } else {
+                v[q] = (T)x;
+              }
+            }
+            *(typename HT::V4*)(ob + tq * os + e0) = v;
+            if constexpr (SPLIT) *(typename HT::V4*)(ob_lo + tq * os + e0) = vl;
+          }
         }
       }
     }
@@ -587,12 +604,15 @@ int temporal_launch(const void* qkv, void* out, const void* qkv_lo, void* out_lo
                     float sl2, hipStream_t s) {
   using TT = typename Half<DT>::T;
   const dim3 grid((nseq + 3) / 4);
-  if (qkv_lo)
-    hipLaunchKernelGGL((temporal_attn_kernel<DT, true>), grid, dim3(256), 0, s, (const TT*)qkv, (TT*)out,
-                       (const TT*)qkv_lo, (TT*)out_lo, nseq, T, D, c, heads, sl2);
-  else
-    hipLaunchKernelGGL((temporal_attn_kernel<DT, false>), grid, dim3(256), 0, s, (const TT*)qkv, (TT*)out,
-                       (const TT*)nullptr, (TT*)nullptr, nseq, T, D, c, heads, sl2);
+#define VDN_TA(SP, NB_)                                                                                          \
+  hipLaunchKernelGGL((temporal_attn_kernel<DT, SP, NB_>), grid, dim3(256), 0, s, (const TT*)qkv, (TT*)out,       \
+                     (const TT*)(SP ? qkv_lo : nullptr), (TT*)(SP ? out_lo : nullptr), nseq, T, D, c, heads, sl2)
+  if (qkv_lo) {
+    if (T <= 32) VDN_TA(true, 1); else VDN_TA(true, 2);
+  } else {
+    if (T <= 32) VDN_TA(false, 1); else VDN_TA(false, 2);
+  }
+#undef VDN_TA
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
@@ -620,7 +640,7 @@ extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* 
 
 extern "C" int vdn_temporal_attn(int dt, const void* qkv, void* out, const void* qkv_lo, void* out_lo, int Bv, int T,
                                  int D, int c, int heads, float scale, vdn_stream stream) {
-  if (!qkv || !out || Bv <= 0 || T <= 0 || T > 32 || D <= 0 || heads <= 0 || c % heads) return VDN_EINVAL;
+  if (!qkv || !out || Bv <= 0 || T <= 0 || T > 64 || D <= 0 || heads <= 0 || c % heads) return VDN_EINVAL;
   if ((qkv_lo == nullptr) != (out_lo == nullptr)) return VDN_EINVAL;
   const int dh = c / heads;
   if ((dh & 7) || dh > 256 || (c & 7)) return VDN_EALIGN;
