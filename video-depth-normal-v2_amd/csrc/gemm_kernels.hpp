@@ -278,10 +278,99 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
 
 // Epilogue straight from registers (4-wave kernels): a store instruction covers 16 rows x 64 (f32) or
 // 32 (half) bytes.
-template <int DT, int TM, int TN, int STORE>
+// Flavours whose outputs are 16-bit planes store 8 consecutive columns per lane (one 16-byte store per plane, half
+// the store instructions, 64-byte row segments): the 8-wave kernels then load W rows into LDS in the order
+// pair8_col() so that a lane's accumulators j = 2u, 2u+1 hold columns 32u + 8 fq + {0..3}, {4..7} of the wave's
+// 64-column slab (instead of 16j + 4 fq + {0..3}).
+template <int STORE>
+constexpr bool vdn_pair8 = (STORE == VDN_STX_FC1 || STORE == VDN_STX_HALF || STORE == VDN_STX_RESHALF1 ||
+                            STORE == VDN_STX_RESHALF2 || STORE == VDN_STX_HEADS);
+// W row (within a 64-row slab) held by LDS row 16 t + r under the paired mapping
+__device__ __forceinline__ int pair8_col(int t, int r) { return (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3); }
+
+// 8 consecutive columns n..n+7 of row m (a0: n..n+3, a1: n+4..n+7) for the plane-output flavours
+template <int DT, int STORE>
+__device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1) {
+  using H = Half<DT>;
+  using T = typename H::T;
+  using V8 = typename H::V8;
+  if (m >= p.M || n >= p.N) return;
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { a[e] = a0[e] + b0[e]; a[4 + e] = a1[e] + b1[e]; }
+  if constexpr (STORE == VDN_STX_FC1) {
+    const f32x4 g0 = gelu4(f32x4{a[0], a[1], a[2], a[3]}), g1 = gelu4(f32x4{a[4], a[5], a[6], a[7]});
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = g0[e]; a[4 + e] = g1[e]; }
+  } else if constexpr (STORE == VDN_STX_HALF) {
+    const float floor_v = p.act == VDN_ACT_RELU ? 0.f : -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], floor_v);
+  } else if constexpr (STORE == VDN_STX_RESHALF1 || STORE == VDN_STX_RESHALF2) {
+    const size_t r1 = (size_t)m * p.ldr1 + n;
+    const V8 rh = *(const V8*)((const T*)p.res1 + r1), rl = *(const V8*)((const T*)p.res1_lo + r1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += (float)rh[e] + (float)rl[e];
+    if constexpr (STORE == VDN_STX_RESHALF2) {
+      const size_t r2 = (size_t)m * p.ldr2 + n;
+      const V8 qh = *(const V8*)((const T*)p.res2 + r2), ql = *(const V8*)((const T*)p.res2_lo + r2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)qh[e] + (float)ql[e];
+    }
+  }
+  V8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    T h0, h1, l0, l1;
+    split2_rtz(a[e], a[e + 1], h0, h1, l0, l1);
+    h[e] = h0; h[e + 1] = h1; l[e] = l0; l[e + 1] = l1;
+  }
+  if constexpr (STORE == VDN_STX_HEADS) {
+    const int hc = p.heads * 64;
+    const int bt = m / p.tokens, tl = m - bt * p.tokens;
+    const int tk = tl + p.tok_off;
+    const int split = n / hc;
+    const int head = (n - split * hc) >> 6, e0 = n & 63;
+    const size_t hb = (size_t)bt * p.heads + head;
+    T* dst = (T*)p.dst[split];
+    T* dlo = (T*)p.dst_lo[split];
+    if (p.transposed[split]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const size_t o = (hb * 64 + e0 + e) * p.tpad + tk;
+        dst[o] = h[e];
+        dlo[o] = l[e];
+      }
+    } else {
+      const size_t o = (hb * p.tpad + tk) * 64 + e0;
+      *(V8*)(dst + o) = h;
+      *(V8*)(dlo + o) = l;
+    }
+  } else {
+    const size_t o = (size_t)m * p.ldc + n;
+    *(V8*)((T*)p.out + o) = h;
+    *(V8*)((T*)p.out_lo + o) = l;
+  }
+}
+
+template <int DT, int TM, int TN, int STORE, bool PAIR = false>
 __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_gemm_desc& p, int mw, int nw, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
   f32x4 bias4[TN], gam4[TN];
+  if constexpr (PAIR) {
+    static_assert(TN == 4, "paired columns: 64-column wave slabs");
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
+      bias4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int u = 0; u < TN / 2; ++u)
+        emit8<DT, STORE>(p, mw + i * 16 + fr, nw + u * 32 + fq * 8, acc[i][2 * u], acc[i][2 * u + 1], bias4[2 * u], bias4[2 * u + 1]);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw + j * 16 + fq * 4;
@@ -746,7 +835,8 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   const T* b_row[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int n = n0 + (wave + 8 * i) * 16 + lr;
+    const int pcw = wave + 8 * i;
+    int n = n0 + (vdn_pair8<STORE> ? (pcw >> 2) * 64 + pair8_col(pcw & 3, lr) : pcw * 16 + lr);
     n = n < p.N ? n : p.N - 1;
     b_row[i] = (const T*)p.W + (size_t)n * p.ldb;
   }
@@ -1021,7 +1111,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] += acc32[(i >> 1) * 2 + (j >> 1)][(i & 1) * 8 + (j & 1) * 4 + e];
 #endif
-  epilogue_regs<DT, TMW, TNW, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  epilogue_regs<DT, TMW, TNW, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1115,7 +1205,7 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
   const char* wp[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int n = n0 + pw[i] * 16 + lr;
+    int n = n0 + (vdn_pair8<STORE> ? (pw[i] >> 2) * 64 + pair8_col(pw[i] & 3, lr) : pw[i] * 16 + lr);
     n = n < p.N ? n : p.N - 1;
     wp[i] = (const char*)((const T*)p.W + (size_t)n * p.ldb + chunk * 8);
     ap[i] = (const char*)(a_row[i] + chunk * 8);
@@ -1271,7 +1361,7 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
 #undef VDN_PHASE
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
 
-  epilogue_regs<DT, 2 * TQ, 4, STORE>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  epilogue_regs<DT, 2 * TQ, 4, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
 }
 
 template <int DT, int BM, int BN, int WM, int WN>
@@ -1325,6 +1415,10 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   } while (0)
   // straight-line epilogue flavours exist for the plain-A kernels at BM 256 / 192 (the encoder / memory linears)
   int fl = epi_flavour(d);
+  // plane-output flavours store 8 columns (16 bytes) per lane: rows and column counts must keep that aligned
+  const bool a8 = !(d.N & 7) && !(d.ldc & 7) && !((uintptr_t)d.out & 15) && !((uintptr_t)d.out_lo & 15) && !(d.ldr1 & 7) &&
+                  !(d.ldr2 & 7) && !(((uintptr_t)d.res1 | (uintptr_t)d.res1_lo | (uintptr_t)d.res2 | (uintptr_t)d.res2_lo) & 15);
+  if (!a8 && fl != VDN_STX_RES && fl != VDN_STX_HEADS) fl = d.store;
   if (d.a_mode == VDN_A_CONV3X3) {
     if (fl != VDN_STX_HALF && fl != VDN_STX_RESHALF1 && fl != VDN_STX_RESHALF2) fl = VDN_ST_PLAIN;
   } else if (BM < 192 || fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) {
