@@ -1155,7 +1155,23 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // Persistent form (launched with fewer workgroups than tiles, a multiple of 8): workgroup b walks the tiles
+  // slot, slot + G/8, ... of ITS XCD's contiguous chunk of the tile order, so the 32 workgroups of an XCD still
+  // sweep consecutive tiles together; the stores of a finished tile drain while the next tile's main loop runs.
+  const int ntiles = tiles_m * tiles_n;
+  const bool persistent = (int)gridDim.x < ntiles;
+  for (int it = 0;; ++it) {
+  int tile;
+  if (persistent) {
+    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int idx = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
+    if (idx >= q8 + (xcd < r8 ? 1 : 0)) break;
+    tile = base + idx;
+  } else {
+    if (it) break;
+    tile = xcd_remap(blockIdx.x, ntiles);
+  }
   int tm_i, tn_i;
   {
     constexpr int GM = 4;
@@ -1362,6 +1378,7 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
 
   epilogue_regs<DT, 2 * TQ, 4, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  }  // tile loop
 }
 
 template <int DT, int BM, int BN, int WM, int WN>
@@ -1431,7 +1448,9 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     const char* p8e = getenv("VDN_GEMM_P8");  // read per launch: tests flip it
     const int p8 = p8e ? atoi(p8e) : 1;
     if (p8 >= (BM == 256 ? 1 : 2)) {
-#define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g, b, lds, s, d)
+      const char* pe = getenv("VDN_GEMM_PERSIST");  // experiment: 256 persistent workgroups
+      const dim3 g8 = (pe && atoi(pe) != 0 && tiles > 256) ? dim3(256) : g;
+#define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g8, b, lds, s, d)
       if (d.a_mode == VDN_A_CONV3X3) {
 #define VDN_CONV_P8(ST) do { if (d.relu_a) VDN_LAUNCH_P8(2, ST); else VDN_LAUNCH_P8(1, ST); } while (0)
         switch (fl) {
