@@ -15,7 +15,6 @@
 //
 // temporal_attn_kernel — <= 32 frames per (pixel, head): one wave per sequence, fragments loaded
 //   straight from global memory (no LDS), same accumulator-as-operand chaining.
-#define VDN_ATTN_EXPERIMENT 1
 #include "common.hpp"
 #include <cstdlib>
 #include <type_traits>
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                          const typename Half<DT>::T* __restrict__ Kl,
                                                          const typename Half<DT>::T* __restrict__ Vtl,
                                                          typename Half<DT>::T* __restrict__ outl, int H, int nq,
-                                                         int nq_pad, int nk, int nk_pad, float scale_log2, int stagger_cycles) {
+                                                         int nq_pad, int nk, int nk_pad, float scale_log2) {
   using HT = Half<DT>;
   using T = typename HT::T;
   using V8 = typename HT::V8;
@@ -583,18 +582,13 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
                  void* outl, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
   using T = typename Half<DT>::T;
   const dim3 grid(((nq + 127) / 128) * B * H);
-  int extra = 0, stag = 0;
-#ifdef VDN_ATTN_EXPERIMENT
-  if (const char* e = getenv("VDN_ATTN_LDS")) extra = atoi(e);
-  if (const char* e = getenv("VDN_ATTN_STAGGER")) stag = atoi(e);
-#endif
   if (Ql)
-    hipLaunchKernelGGL((flash_attn_kernel<DT, true>), grid, dim3(256), 65536 + extra, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2, stag);
+    hipLaunchKernelGGL((flash_attn_kernel<DT, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
   else
-    hipLaunchKernelGGL((flash_attn_kernel<DT, false>), grid, dim3(256), 32768 + extra, s, (const T*)Q, (const T*)K, (const T*)Vt,
+    hipLaunchKernelGGL((flash_attn_kernel<DT, false>), grid, dim3(256), 32768, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)outl, H, nq, nq_pad, nk,
-                       nk_pad, sl2, stag);
+                       nk_pad, sl2);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
