@@ -153,7 +153,13 @@ __device__ __forceinline__ void stage_barrier() {
 __device__ __forceinline__ void split_rtz(float x, _Float16& hi, _Float16& lo) {
   const f16x2 p = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
   hi = p[0];
+#ifdef VDN_SPLIT_CLASSIC
   lo = (_Float16)(x - (float)hi);
+#else
+  uint32_t lp;  // fp16(x - hi) by one mixed-precision FMA (see split2_rtz)
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(__builtin_bit_cast(uint32_t, p)), "v"(x));
+  lo = __builtin_bit_cast(f16x2, lp)[0];
+#endif
 }
 __device__ __forceinline__ void split_rtz(float x, __bf16& hi, __bf16& lo) {
   const uint32_t u = __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u;  // truncate mantissa
@@ -167,9 +173,22 @@ __device__ __forceinline__ void split2_rtz(float x0, float x1, _Float16& h0, _Fl
   const f16x2 p = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
   h0 = p[0];
   h1 = p[1];
+  // lo = fp16(x - hi) in ONE instruction per value: the mixed-precision FMA reads the fp16 hi half directly
+  // (no v_cvt_f32_f16), multiplies by -1, adds the fp32 x and rounds the result to fp16 (3 instead of 5 VALU
+  // instructions per pair; the compiler's own choice was cvt + cvt + pk_add + cvt_pk)
+#ifdef VDN_SPLIT_CLASSIC  // A/B builds only (tools/build_variant.sh)
   const f32x2 d = f32x2{x0, x1} - f32x2{(float)p[0], (float)p[1]};
   l0 = (_Float16)d[0];
   l1 = (_Float16)d[1];
+#else
+  const uint32_t hp = __builtin_bit_cast(uint32_t, p);
+  uint32_t lp;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(x1));
+  const f16x2 q = __builtin_bit_cast(f16x2, lp);
+  l0 = q[0];
+  l1 = q[1];
+#endif
 }
 __device__ __forceinline__ void split2_rtz(float x0, float x1, __bf16& h0, __bf16& h1, __bf16& l0, __bf16& l1) {
   split_rtz(x0, h0, l0);
