@@ -35,6 +35,31 @@ constexpr int BK = 64;
 // LayerScale factor, loaded ONCE per wave before the first store (0 / 0 / 1 when the operand is absent): a
 // load inside the store loop waits on vmcnt, which on gfx9 also counts the stores issued before it, so
 // every group paid a full store round trip (measured: 10 us of "math" per tile round that was latency).
+// Implicit-GEMM 3x3 gather, fast path for the (ci/64, tap, ...) K order: per 16-row piece a pointer to the centre
+// tap (plus this lane's 16-byte chunk) and a 9-bit "tap lies inside the image" mask are computed once; a K step
+// then costs a wave-uniform offset, one bit test and one 64-bit add per piece instead of ~25 VALU of index math.
+struct ConvTap {
+  const void* center;
+  unsigned ok9;
+};
+template <typename T>
+__device__ __forceinline__ ConvTap conv_tap_setup(const T* image, int iy0, int ix0, int chunk_elems, const vdn_gemm_desc& p) {
+  ConvTap c;
+  c.center = image + ((ptrdiff_t)(iy0 + 1) * p.cW + (ix0 + 1)) * p.cC + chunk_elems;
+  c.ok9 = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+    c.ok9 |= (unsigned)((iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW)) << t;
+  }
+  return c;
+}
+// element offset of tap `tap` (0..8, wave-uniform) relative to the centre
+__device__ __forceinline__ int conv_tap_offset(int tap, const vdn_gemm_desc& p) {
+  const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+  return ((ky - 1) * p.cW + (kx - 1)) * p.cC;
+}
+
 // internal store codes (never in a descriptor): specialised epilogues, see emit4 / epi_flavour
 constexpr int VDN_STX_FC1 = 100, VDN_STX_RES = 101, VDN_STX_HEADS = 102, VDN_STX_HALF = 103, VDN_STX_RESHALF1 = 104,
               VDN_STX_RESHALF2 = 105;
@@ -505,6 +530,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
   }
   const T* zeros = (const T*)p.zeros;
   const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+  ConvTap ctap[A_IT];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ctap[i] = conv_tap_setup(a_row[i], a_iy[i], a_ix[i], chunk * 8, p);
+  }
 
   // K segments: [A_hi x W_hi] (+ [A_hi x W_lo]) (+ [A_lo x W_hi]) — the split-precision planes are
   // just further stretches of the same accumulation loop, selected by a plane byte offset.
@@ -537,11 +567,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vdn_gemm_desc p) {
         ci = k - tap * p.cC;
       }
       const int ky = tap / 3, kx = tap - ky * 3;
+      const int fast_off = (p.conv_korder && tap < 9) ? conv_tap_offset(tap, p) + (kt / 9) * 64 : 0;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-        const bool ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
-        const char* src = ok ? (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci) + ad : (const char*)zeros;
+        bool ok;
+        const char* src;
+        if (p.conv_korder) {
+          ok = (tap < 9) & ((ctap[i].ok9 >> (tap < 9 ? tap : 0)) & 1);
+          src = (const char*)((const T*)ctap[i].center + fast_off) + ad;
+        } else {
+          const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+          ok = (tap < 9) & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+          src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci) + ad;
+        }
+        src = ok ? src : (const char*)zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sA + (i * 4 + wave) * 1024),
                                          16, 0, 0);
@@ -675,6 +714,11 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
   const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
   const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
   const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+  ConvTap ctap[2];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ctap[i] = conv_tap_setup(a_row[i], a_iy[i], a_ix[i], chunk * 8, p);
+  }
 
 #define VDN_GLDS(src, dst)                                                                \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
@@ -706,9 +750,15 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const vdn_gemm_desc p) {
       const char* src;
       bool ok = kok;
       if constexpr (CONV) {
-        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-        ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
-        src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+        if (p.conv_korder) {
+          const int tap = ky * 3 + kx;
+          ok = ok & ((ctap[i].ok9 >> tap) & 1);
+          src = (const char*)((const T*)ctap[i].center + (kok ? conv_tap_offset(tap, p) : 0) + (ci - chunk * 8));
+        } else {
+          const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+          ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+          src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+        }
       } else {
         src = (const char*)(a_row[i] + k);
       }
@@ -844,6 +894,11 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   const ptrdiff_t a_delta = (const char*)p.A_lo - (const char*)p.A;
   const ptrdiff_t w_delta = (const char*)p.W_lo - (const char*)p.W;
   const float inv_cin = CONV ? 1.0f / (float)(p.cC >> 3) : 0.f;
+  ConvTap ctap[2];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ctap[i] = conv_tap_setup(a_row[i], a_iy[i], a_ix[i], chunk * 8, p);
+  }
 
 #define VDN_GLDS(src, dst)                                                                \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
@@ -876,9 +931,15 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
         const char* src;
         bool ok = kok;
         if constexpr (CONV) {
-          const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-          ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
-          src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+          if (p.conv_korder) {
+            const int tap = ky * 3 + kx;
+            ok = ok & ((ctap[i].ok9 >> tap) & 1);
+            src = (const char*)((const T*)ctap[i].center + (kok ? conv_tap_offset(tap, p) : 0) + (ci - chunk * 8));
+          } else {
+            const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+            ok = ok & (iy >= 0) & (iy < p.cH) & (ix >= 0) & (ix < p.cW);
+            src = (const char*)(a_row[i] + ((size_t)iy * p.cW + ix) * p.cC + ci);
+          }
         } else {
           src = (const char*)(a_row[i] + k);
         }
