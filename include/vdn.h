@@ -116,6 +116,10 @@ typedef struct vdn_gemm_desc {
    * consecutive K steps read the same pixels' neighbouring taps / the two halves of one 128-byte
    * line, so the 9x re-read of the input map is served from L2 instead of HBM.                   */
   int32_t conv_korder;
+  /* Tile-shape hint: how many CUs this launch can count on (0 = the whole chip, 256). A caller that keeps two
+   * independent launch streams busy passes 128: the M tile is then chosen for the share of the machine one
+   * kernel really gets while the other stream's kernels co-run (measured +3.6 % end to end). Never changes results. */
+  int32_t cu_hint;
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);

@@ -1587,13 +1587,15 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
 template <int DT> int big_entry(const vdn_gemm_desc& d, int bm, hipStream_t s);  // defined in gemm_big_*.hip
 
 // Pick the M tile that wastes the fewest CU-rounds: cost = rounds(256 CUs) * BM, padded work included.
-inline int pick_bm(int M, int N) {
+inline int pick_bm(int M, int N, int cu_hint) {
   const int tn = (N + 255) / 256;
+  const char* ce = getenv("VDN_GEMM_CUS");  // experiments only
+  const int cus = ce ? atoi(ce) : (cu_hint > 0 && cu_hint <= 256 ? cu_hint : 256);  // CUs one launch can count on
   int best = 0;
   double best_cost = 1e30;
   for (int bm : {256, 192, 128}) {
     const long tiles = (long)((M + bm - 1) / bm) * tn;
-    const long rounds = (tiles + 255) / 256;
+    const long rounds = (tiles + cus - 1) / cus;
     const double cost = (double)rounds * bm * (bm == 128 ? 1.12 : (bm == 192 ? 1.04 : 1.0));  // smaller tiles feed worse
     if (cost < best_cost) { best_cost = cost; best = bm; }
   }
@@ -1605,7 +1607,7 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024 &&
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
     const char* force = getenv("VDN_GEMM_BM");
-    const int bm = force ? atoi(force) : pick_bm(d.M, d.N);
+    const int bm = force ? atoi(force) : pick_bm(d.M, d.N, d.cu_hint);
     if (bm == 256 || bm == 192 || bm == 128) return big_entry<DT>(d, bm, s);
   }
   if (d.A_lo && d.W_lo && (d.store == VDN_ST_HEADS || d.N > 64)) return launch_x3<DT>(d, s);

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("rope_cs", fp), ("rope_mod", i32),
         ("ck", i32), ("cout", i32), ("zeros", vp),
         ("A_lo", vp), ("W_lo", vp), ("out_lo", vp), ("dst_lo", vp * 3), ("res1_lo", vp), ("res2_lo", vp),
-        ("conv_korder", i32),
+        ("conv_korder", i32), ("cu_hint", i32),
     ]
 
 

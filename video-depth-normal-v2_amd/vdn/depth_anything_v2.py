@@ -153,8 +153,11 @@ class DepthAnythingV2(_EngineOwner):
         B = x.shape[0]
         nl = int(os.environ.get("VDN_STREAMS", "2"))
         if nl < 2 or B < 4 or B % nl:
+            rt.cu_hint = 0
             return self._forward_lane(dict(rt=rt, enc=e["enc"], mem=e["mem"], head=e["head"]), x, _pre_relu)
         lanes = self._stream_lanes(nl)
+        for ln in lanes:
+            ln["rt"].cu_hint = 256 // nl  # each lane's GEMM tiles are sized for its share of the CUs
         cur = torch.cuda.current_stream(rt.device)
         outs = []
         for ln, xs in zip(lanes, x.chunk(nl)):

@@ -85,6 +85,7 @@ class Runtime:
         self._plans: Dict[object, list] = {}
         self._rec: Optional[list] = None
         self._keep: List[object] = []
+        self.cu_hint = 0  # vdn_gemm_desc.cu_hint: 0 = whole chip; lanes that co-run set their share
         self.timing: Optional[list] = None  # bench.py: [(tag, start_event, end_event)] for tagged launches
 
     # ------------------------------------------------------------------ memory
@@ -212,6 +213,7 @@ class Runtime:
             d.ck, d.cout = convt["k"], convt["cout"]
             d.cB, d.cH, d.cW = convt["B"], convt["H"], convt["W"]
         d.zeros = self.zeros.data_ptr()
+        d.cu_hint = self.cu_hint
         self._launch(abi.lib.vdn_gemm, C.byref(d), tag=tag)
         self._keep_alive(d)
         return out
