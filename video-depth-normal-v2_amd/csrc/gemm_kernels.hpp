@@ -1596,7 +1596,9 @@ inline int pick_bm(int M, int N, int cu_hint) {
   for (int bm : {256, 192, 128}) {
     const long tiles = (long)((M + bm - 1) / bm) * tn;
     const long rounds = (tiles + cus - 1) / cus;
-    const double cost = (double)rounds * bm * (bm == 128 ? 1.12 : (bm == 192 ? 1.04 : 1.0));  // smaller tiles feed worse
+    static const double f128 = getenv("VDN_GEMM_F128") ? atof(getenv("VDN_GEMM_F128")) : 1.12;
+    static const double f192 = getenv("VDN_GEMM_F192") ? atof(getenv("VDN_GEMM_F192")) : 1.04;
+    const double cost = (double)rounds * bm * (bm == 128 ? f128 : (bm == 192 ? f192 : 1.0));  // smaller tiles feed worse
     if (cost < best_cost) { best_cost = cost; best = bm; }
   }
   return best;
