@@ -1610,7 +1610,14 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
     const char* force = getenv("VDN_GEMM_BM");
     const int bm = force ? atoi(force) : pick_bm(d.M, d.N, d.cu_hint);
-    if (bm == 256 || bm == 192 || bm == 128) return big_entry<DT>(d, bm, s);
+    // small problems (batch 1: M = 1370): a grid of 128 x 256 tiles covers a fraction of the chip; the 4-wave 128 x 128
+    // kernel launches twice the workgroups (two per CU) with half the K-loop work each
+    // (batch 1: 15.9 -> 14.8 ms per frame, batch 2: 18.4 -> 17.3 ms with the threshold at 96 tiles)
+    const char* mt = getenv("VDN_GEMM_MIN_TILES");  // experiment knob; 0 disables
+    const long min_tiles = mt ? atol(mt) : 96;
+    const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
+    const bool small = !force && min_tiles > 0 && tiles128 < min_tiles && d.a_mode != VDN_A_CONV3X3;
+    if (!small && (bm == 256 || bm == 192 || bm == 128)) return big_entry<DT>(d, bm, s);
   }
   if (d.A_lo && d.W_lo && (d.store == VDN_ST_HEADS || d.N > 64)) return launch_x3<DT>(d, s);
   if (d.store == VDN_ST_HEADS || d.N > 64) return launch_tile<DT, 128, 128, 2, 2>(d, s);
