@@ -61,7 +61,7 @@ def main():
     if a.lanes is not None:
         os.environ["VDN_STREAMS"] = str(a.lanes)
     lanes = int(os.environ.get("VDN_STREAMS", "2")) if a.workload == "stream" else 1
-    if lanes < 2 or a.batch < 4 or a.batch % lanes:
+    if lanes < 2 or a.batch < int(os.environ.get("VDN_LANE_MIN_BATCH", "4")) or a.batch % lanes:
         lanes = 1
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

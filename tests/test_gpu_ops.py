@@ -759,3 +759,23 @@ def test_refiner_scale_pack_finish_kernels(rt):
     close(out.cpu(), (d + (depth * 1.3 + 0.05)) * 65535.0, 1e-6)
     rt.refine_finish(None, depth.to(DEV), 1.3, 0.05, 65535.0, False, out)
     close(out.cpu(), depth * 65535.0, 1e-6)
+
+
+def test_cu_hint_only_changes_the_tiling(rt3):
+    """vdn_gemm_desc.cu_hint (the share of the chip a co-running lane can count on) picks another M tile and must
+    not change the result beyond fp32 summation order."""
+    from vdn import pack
+    M, N, K = 5480, 1024, 256
+    a = rnd(M, K, seed=700)
+    w = rnd(N, K, seed=701, scale=1 / math.sqrt(K))
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    outs = []
+    for hint in (0, 128, 64):
+        rt3.cu_hint = hint
+        o = torch.empty(M, N, device=DEV)
+        rt3.gemm(A, W, M, N, K, out=o)
+        outs.append(o.cpu())
+    rt3.cu_hint = 0
+    ref = (a.double() @ w.double().t()).float()
+    for o in outs:
+        close(o, ref, 3e-6)

@@ -152,7 +152,7 @@ class DepthAnythingV2(_EngineOwner):
         x = x.to(device=rt.device, dtype=torch.float32).contiguous()
         B = x.shape[0]
         nl = int(os.environ.get("VDN_STREAMS", "2"))
-        if nl < 2 or B < 4 or B % nl:
+        if nl < 2 or B < int(os.environ.get("VDN_LANE_MIN_BATCH", "4")) or B % nl:
             rt.cu_hint = 0
             return self._forward_lane(dict(rt=rt, enc=e["enc"], mem=e["mem"], head=e["head"]), x, _pre_relu)
         lanes = self._stream_lanes(nl)
