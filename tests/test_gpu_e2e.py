@@ -237,3 +237,24 @@ def test_depth_refiner_v4_v5_against_reference_fixture(version, name):
     # two clips in one batch are independent
     both = m.forward(torch.cat([x, x * 0.5 + 100.0]).cuda()).cpu()
     assert rel_l2(both[0], g["out"]) < TOL
+
+
+@pytest.mark.parametrize("use_residual,input_normal", [(False, True), (True, False)])
+def test_depth_refiner_flags_against_oracle(use_residual, input_normal):
+    """The v5 wrapper's constructor switches (video_depth_model_v5.py:135-136,172-189): no shift/residual,
+    depth broadcast to 3 channels instead of Sobel normals — against the oracle on a 2-frame clip."""
+    import vdn
+    from oracle import ref_cpu as O
+    from vdn import synth
+    from vdn.video_depth_model_v5 import VideoDepthAnything
+    sd = synth_sd("R5", "vits")
+    m = VideoDepthAnything(use_residual=use_residual, input_normal=input_normal, **vdn.MODEL_CONFIGS["vits"])
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    x = torch.from_numpy(synth.depth_clip(77, 2, 70, 95))[None]
+    with torch.no_grad():
+        ref = O.depth_refiner_forward(sd, x, "vits", version=5, use_residual=use_residual, input_normal=input_normal)
+    out = m.forward(x.cuda()).cpu()
+    e = rel_l2(out, ref)
+    print(f"[refiner v5 residual={use_residual} normals={input_normal}] vs oracle {e:.2e}")
+    assert e < TOL
