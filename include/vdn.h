@@ -120,6 +120,13 @@ typedef struct vdn_gemm_desc {
    * independent launch streams busy passes 128: the M tile is then chosen for the share of the machine one
    * kernel really gets while the other stream's kernels co-run (measured +3.6 % end to end). Never changes results. */
   int32_t cu_hint;
+  /* Optional split-K workspace (f32, caller-owned, >= 16-byte aligned): a 3x3 convolution whose tile grid covers
+   * only a fraction of the chip (low-resolution maps with 9*Cin = 9216-deep reductions) is cut into up to 8 K
+   * slices that write partial sums here and a second kernel adds them in a fixed order and applies the epilogue
+   * (deterministic). NULL / 0 disables. `ksplit` is set by the library and must be 0 on entry.                */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
+  int32_t ksplit;
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);

@@ -779,3 +779,39 @@ def test_cu_hint_only_changes_the_tiling(rt3):
     ref = (a.double() @ w.double().t()).float()
     for o in outs:
         close(o, ref, 3e-6)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,two,relu_a", [(1, 19, 19, 256, 256, False, False), (2, 19, 19, 1024, 256, False, False),
+                                                    (1, 37, 37, 256, 256, True, True), (4, 19, 19, 512, 1024, False, False)])
+def test_x3_conv_split_k_matches_single_pass(rt3, B, H, W, Ci, Co, two, relu_a, monkeypatch):
+    """Low-resolution convolutions with deep reductions run as K slices + an ordered reduce (vdn.h: splitk_ws):
+    against fp64 and against the unsplit kernel (VDN_GEMM_NOSPLITK), bitwise repeatable."""
+    from vdn import pack, _abi
+    x = rnd(B, H, W, Ci, seed=800)
+    w = rnd(Co, Ci, 3, 3, seed=801, scale=1 / math.sqrt(9 * Ci))
+    b = rnd(Co, seed=802)
+    r1, r2 = rnd(B * H * W, Co, seed=803), rnd(B * H * W, Co, seed=804)
+    xin = F.relu(x) if relu_a else x
+    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    if two:
+        ref = ref + r1.double() + r2.double()
+    ref = ref.float()
+    xa = rt3.hbuf(f"t_sk_a{Ci}", (B * H * W, Ci))
+    xf = x.reshape(-1, Ci).to(DEV)
+    h_rtn = xf.half()
+    hi = torch.where(h_rtn.float().abs() > xf.abs(), torch.nextafter(h_rtn, torch.zeros_like(h_rtn)), h_rtn)
+    xa.hi.copy_(hi)
+    xa.lo.copy_((xf - hi.float()).half())
+    wp = pack.conv3x3(w.to(DEV), rt3.prec)
+    kw = dict(bias=b.to(DEV), relu_a=relu_a, conv=dict(B=B, H=H, W=W, C=Ci, OH=H, OW=W, stride=1))
+    if two:
+        kw.update(res1=rt3.to_half(r1.to(DEV)), res2=rt3.to_half(r2.to(DEV)))
+    out = rt3.hbuf(f"t_sk_o{Ci}_{Co}", (B * H * W, Co))
+    rt3.gemm(xa, wp, B * H * W, Co, 9 * Ci, out=out, **kw)
+    close(out.float(), ref, 5e-6)
+    first = (out.hi.clone(), out.lo.clone())
+    rt3.gemm(xa, wp, B * H * W, Co, 9 * Ci, out=out, **kw)
+    assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
+    monkeypatch.setenv("VDN_GEMM_NOSPLITK", "1")
+    rt3.gemm(xa, wp, B * H * W, Co, 9 * Ci, out=out, **kw)
+    close(out.float(), first[0].float() + first[1].float(), 3e-6)

@@ -25,6 +25,8 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
     return VDN_EUNSUPPORTED;
   }
   if (d.N & 3) return VDN_EALIGN;  // the epilogue stores 4 columns per lane
+  if (d.ksplit != 0 || d.splitk_ws_bytes < 0 || (d.splitk_ws == nullptr) != (d.splitk_ws_bytes == 0)) return VDN_EINVAL;
+  if ((uintptr_t)d.splitk_ws & 15) return VDN_EALIGN;
   if (((uintptr_t)d.A_lo | (uintptr_t)d.W_lo | (uintptr_t)d.out_lo) & 15) return VDN_EALIGN;
   if (d.out_lo && (d.out_dt == VDN_F32 || !d.out)) return VDN_EINVAL;
   if ((d.res1 && (d.ldr1 & 3)) || (d.res2 && (d.ldr2 & 3))) return VDN_EALIGN;

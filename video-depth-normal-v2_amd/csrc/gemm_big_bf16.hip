@@ -6,4 +6,7 @@ template <> int big_entry<VDN_BF16>(const vdn_gemm_desc& d, int bm, hipStream_t 
   if (bm == 192) return launch_x3_big<VDN_BF16, 192>(d, s);
   return launch_x3_big<VDN_BF16, 128>(d, s);
 }
+template <> int splitk_entry<VDN_BF16>(const vdn_gemm_desc& d, int ksplit, int fl, hipStream_t s) {
+  return launch_splitk<VDN_BF16>(d, ksplit, fl, s);
+}
 }

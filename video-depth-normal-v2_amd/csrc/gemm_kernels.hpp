@@ -62,7 +62,7 @@ __device__ __forceinline__ int conv_tap_offset(int tap, const vdn_gemm_desc& p) 
 
 // internal store codes (never in a descriptor): specialised epilogues, see emit4 / epi_flavour
 constexpr int VDN_STX_FC1 = 100, VDN_STX_RES = 101, VDN_STX_HEADS = 102, VDN_STX_HALF = 103, VDN_STX_RESHALF1 = 104,
-              VDN_STX_RESHALF2 = 105;
+              VDN_STX_RESHALF2 = 105, VDN_STX_SPLITK = 106;
 
 // Which straight-line flavour (if any) computes exactly what descriptor `d` asks for.
 __host__ __device__ inline int epi_flavour(const vdn_gemm_desc& d) {
@@ -98,7 +98,10 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
   // ---- straight-line flavours of the hot epilogues (chosen on the host by epi_flavour()): the generic code
   // below tests ~40 wave-uniform descriptor fields per group, and with 32 groups per lane and only two waves
   // per SIMD those scalar branches were 12 us of every 31 us tile round at K = 32 (tools/gemm_ablate.sh).
-  if constexpr (STORE == VDN_STX_FC1) {  // bias + GELU -> split half planes, plain rows
+  if constexpr (STORE == VDN_STX_SPLITK) {  // raw partial sums of one K slice (p.out / p.ldc were redirected to the slice)
+    *(f32x4*)((float*)p.out + (size_t)m * p.ldc + n) = a;
+    return;
+  } else if constexpr (STORE == VDN_STX_FC1) {  // bias + GELU -> split half planes, plain rows
     a = gelu4(a + bias_a);
     const size_t o = (size_t)m * p.ldc + n;
     typename H::V4 h, l;
@@ -846,9 +849,13 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
+  // split-K (convolutions only): the grid is ksplit copies of the tile grid, slice s reduces K steps [kt0, kt0 + nk)
+  const int ntiles = tiles_m * tiles_n;
+  const int slice = (STORE == VDN_STX_SPLITK) ? (int)blockIdx.x / ntiles : 0;
+  const int bid = (int)blockIdx.x - slice * ntiles;
   // tile order inside an XCD's run: groups of 4 m-tiles walk n first, so that the ~32 tiles an
   // XCD has in flight share A rows 8-fold and W columns 4-fold through its L2
-  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tile = xcd_remap(bid, ntiles);
   int tm_i, tn_i;
   {
     constexpr int GM = 4;
@@ -859,6 +866,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
     tm_i = g * GM + (r - tn_i * gm);
   }
   const int m0 = tm_i * BM, n0 = tn_i * BN;
+  const int nk_total = (AMODE == 1 || AMODE == 2) ? p.ldb / BK3 : p.K / BK3;
+  const int nk_slice = (STORE == VDN_STX_SPLITK) ? (nk_total + p.ksplit - 1) / p.ksplit : nk_total;
+  const int kt0 = slice * nk_slice;
 
   const int lr = lane >> 2;
   const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
@@ -905,6 +915,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
   auto stage = [&](int buf, int kt) {
     char* s0 = smem + buf * STAGE;
+    kt += kt0;  // absolute K step of this slice
     const int k = kt * BK3 + chunk * 8;
     int ky = 0, kx = 0, ci = 0;
     bool kok = k < p.K;
@@ -1014,7 +1025,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   // plain rows advance by pointer increments with no K-tail select: stop at K (a multiple of 32 on this
   // path), NOT at the padded weight stride — reading A columns K..ldb would run into the next row and,
   // on the last row, past the buffer (0 x NaN = NaN even though the padded weights are zero).
-  const int nk = CONV ? p.ldb / BK3 : p.K / BK3;
+  const int nk = (nk_total - kt0) < nk_slice ? (nk_total - kt0) : nk_slice;
   if constexpr (!PIPE) {
     if constexpr (CONV) stage(0, 0); else stage_plain(0);
     stage_barrier();
@@ -1172,7 +1183,14 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] += acc32[(i >> 1) * 2 + (j >> 1)][(i & 1) * 8 + (j & 1) * 4 + e];
 #endif
-  epilogue_regs<DT, TMW, TNW, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  if constexpr (STORE == VDN_STX_SPLITK) {
+    vdn_gemm_desc q = p;
+    q.out = (float*)p.splitk_ws + (size_t)slice * p.M * p.N;
+    q.ldc = p.N;
+    epilogue_regs<DT, TMW, TNW, STORE, false>(acc, q, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  } else {
+    epilogue_regs<DT, TMW, TNW, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1586,6 +1604,43 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
 
 template <int DT> int big_entry(const vdn_gemm_desc& d, int bm, hipStream_t s);  // defined in gemm_big_*.hip
 
+// ---- split-K for convolutions whose tile grid covers a fraction of the chip (include/vdn.h: splitk_ws)
+// second pass: partial sums of the K slices added in slice order, then the SAME straight-line epilogue flavour
+template <int DT, int FL>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const vdn_gemm_desc p) {
+  const int n4 = p.N >> 2;
+  const size_t total = (size_t)p.M * n4, mn = (size_t)p.M * p.N;
+  const float* ws = (const float*)p.splitk_ws;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+    f32x4 a = *(const f32x4*)(ws + (size_t)m * p.N + n);
+    for (int sl = 1; sl < p.ksplit; ++sl) a += *(const f32x4*)(ws + sl * mn + (size_t)m * p.N + n);
+    const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    emit4<DT, FL>(p, m, n, a, a, b4, b4, one);
+  }
+}
+
+template <int DT>
+int launch_splitk(const vdn_gemm_desc& d0, int ksplit, int fl, hipStream_t s) {
+  vdn_gemm_desc d = d0;
+  d.ksplit = ksplit;
+  const int tiles = ((d.M + 127) / 128) * ((d.N + 255) / 256);
+  const size_t lds = 2 * (size_t)(2 * 128 * 64 + 2 * 256 * 64);
+  if (d.relu_a) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
+  else hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 1, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
+  const size_t work = (size_t)d.M * (d.N >> 2);
+  const dim3 g((unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096));
+  switch (fl) {
+    case VDN_STX_HALF: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_HALF>), g, dim3(256), 0, s, d); break;
+    case VDN_STX_RESHALF1: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_RESHALF1>), g, dim3(256), 0, s, d); break;
+    default: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_RESHALF2>), g, dim3(256), 0, s, d); break;
+  }
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+template <int DT> int splitk_entry(const vdn_gemm_desc& d, int ksplit, int fl, hipStream_t s);  // defined in gemm_big_*.hip
+
 // Pick the M tile that wastes the fewest CU-rounds: cost = rounds(256 CUs) * BM, padded work included.
 inline int pick_bm(int M, int N, int cu_hint) {
   const int tn = (N + 255) / 256;
@@ -1609,6 +1664,21 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024 &&
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
     const char* force = getenv("VDN_GEMM_BM");
+    if (d.a_mode == VDN_A_CONV3X3 && d.splitk_ws && !force && !(d.N & 3) && !getenv("VDN_GEMM_NOSPLITK")) {
+      const int fl = epi_flavour(d);
+      const int cus = d.cu_hint > 0 && d.cu_hint <= 256 ? d.cu_hint : 256;
+      const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
+      const int nk_total = d.ldb / 32;
+      if ((fl == VDN_STX_HALF || fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) && tiles128 * 2 <= cus && nk_total >= 64) {
+        long ks = cus / tiles128;
+        ks = ks < 8 ? ks : 8;
+        ks = ks < nk_total / 16 ? ks : nk_total / 16;
+        const long fit = d.splitk_ws_bytes / ((long)d.M * d.N * 4);
+        ks = ks < fit ? ks : fit;
+        while (ks >= 2 && (ks - 1) * ((nk_total + ks - 1) / ks) >= nk_total) --ks;  // every slice non-empty
+        if (ks >= 2) return splitk_entry<DT>(d, (int)ks, fl, s);
+      }
+    }
     const int bm = force ? atoi(force) : pick_bm(d.M, d.N, d.cu_hint);
     // small problems (batch 1: M = 1370): a grid of 128 x 256 tiles covers a fraction of the chip; the 4-wave 128 x 128
     // kernel launches twice the workgroups (two per CU) with half the K-loop work each

@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("ck", i32), ("cout", i32), ("zeros", vp),
         ("A_lo", vp), ("W_lo", vp), ("out_lo", vp), ("dst_lo", vp * 3), ("res1_lo", vp), ("res2_lo", vp),
         ("conv_korder", i32), ("cu_hint", i32),
+        ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("ksplit", i32),
     ]
 
 

@@ -214,6 +214,9 @@ class Runtime:
             d.cB, d.cH, d.cW = convt["B"], convt["H"], convt["W"]
         d.zeros = self.zeros.data_ptr()
         d.cu_hint = self.cu_hint
+        if conv is not None and self.split:  # split-K scratch for low-occupancy convolutions (include/vdn.h)
+            ws = self.buf("splitk_ws", (32 * 1024 * 1024,), torch.float32)
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
         self._launch(abi.lib.vdn_gemm, C.byref(d), tag=tag)
         self._keep_alive(d)
         return out
