@@ -815,3 +815,29 @@ def test_x3_conv_split_k_matches_single_pass(rt3, B, H, W, Ci, Co, two, relu_a, 
     monkeypatch.setenv("VDN_GEMM_NOSPLITK", "1")
     rt3.gemm(xa, wp, B * H * W, Co, 9 * Ci, out=out, **kw)
     close(out.float(), first[0].float() + first[1].float(), 3e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 4096), (1369, 1024, 1024), (361, 256, 2048)])
+def test_x3_plain_split_k_residual_and_planes(rt3, M, N, K, monkeypatch):
+    """Small-M linears (batch-1 encoder: 44 tiles of 128x256) run as K slices + ordered reduce: the in-place
+    LayerScale residual update and a plane-output projection, against fp64 and the unsplit kernel."""
+    from vdn import pack
+    a = rnd(M, K, seed=810)
+    w = rnd(N, K, seed=811, scale=1 / math.sqrt(K))
+    b, g = rnd(N, seed=812), rnd(N, seed=813)
+    x = rnd(M, N, seed=814)
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    ref = (x.double() + (a.double() @ w.double().t() + b.double()) * g.double()).float()
+    xd = x.clone().to(DEV)
+    rt3.gemm(A, W, M, N, K, out=xd, bias=b.to(DEV), gamma=g.to(DEV), res1=xd)
+    close(xd, ref, 3e-6)
+    oh = rt3.hbuf(f"t_psk_{M}_{N}", (M, N))
+    rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV))
+    close(oh.float(), (a.double() @ w.double().t() + b.double()).float(), 3e-6)
+    first = (oh.hi.clone(), oh.lo.clone())
+    rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV))
+    assert torch.equal(oh.hi, first[0]) and torch.equal(oh.lo, first[1])
+    monkeypatch.setenv("VDN_GEMM_NOSPLITK", "1")
+    xd2 = x.clone().to(DEV)
+    rt3.gemm(A, W, M, N, K, out=xd2, bias=b.to(DEV), gamma=g.to(DEV), res1=xd2)
+    close(xd2, xd, 3e-6)

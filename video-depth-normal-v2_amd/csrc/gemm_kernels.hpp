@@ -971,9 +971,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   const char* wp[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    ap[i][0] = (const char*)(a_row[i] + chunk * 8);
+    ap[i][0] = (const char*)(a_row[i] + chunk * 8) + (size_t)kt0 * 64;  // kt0: first K step of this split-K slice
     ap[i][1] = ap[i][0] + a_delta;
-    wp[i][0] = (const char*)(b_row[i] + chunk * 8);
+    wp[i][0] = (const char*)(b_row[i] + chunk * 8) + (size_t)kt0 * 64;
     wp[i][1] = wp[i][0] + w_delta;
   }
   auto stage_plain = [&](int buf) {
@@ -1617,7 +1617,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vdn_gemm_desc 
     f32x4 a = *(const f32x4*)(ws + (size_t)m * p.N + n);
     for (int sl = 1; sl < p.ksplit; ++sl) a += *(const f32x4*)(ws + sl * mn + (size_t)m * p.N + n);
     const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    emit4<DT, FL>(p, m, n, a, a, b4, b4, one);
+    const f32x4 g4 = p.gamma ? *(const f32x4*)(p.gamma + n) : one;
+    emit4<DT, FL>(p, m, n, a, a, b4, b4, g4);
   }
 }
 
@@ -1627,13 +1628,15 @@ int launch_splitk(const vdn_gemm_desc& d0, int ksplit, int fl, hipStream_t s) {
   d.ksplit = ksplit;
   const int tiles = ((d.M + 127) / 128) * ((d.N + 255) / 256);
   const size_t lds = 2 * (size_t)(2 * 128 * 64 + 2 * 256 * 64);
-  if (d.relu_a) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
+  if (d.a_mode != VDN_A_CONV3X3) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
+  else if (d.relu_a) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
   else hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 1, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
   const size_t work = (size_t)d.M * (d.N >> 2);
   const dim3 g((unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096));
   switch (fl) {
     case VDN_STX_HALF: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_HALF>), g, dim3(256), 0, s, d); break;
     case VDN_STX_RESHALF1: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_RESHALF1>), g, dim3(256), 0, s, d); break;
+    case VDN_STX_RES: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_RES>), g, dim3(256), 0, s, d); break;
     default: hipLaunchKernelGGL((splitk_reduce_kernel<DT, VDN_STX_RESHALF2>), g, dim3(256), 0, s, d); break;
   }
   VDN_CHECK_LAUNCH();
@@ -1664,12 +1667,14 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024 &&
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
     const char* force = getenv("VDN_GEMM_BM");
-    if (d.a_mode == VDN_A_CONV3X3 && d.splitk_ws && !force && !(d.N & 3) && !getenv("VDN_GEMM_NOSPLITK")) {
+    if (d.splitk_ws && !force && !(d.N & 3) && !getenv("VDN_GEMM_NOSPLITK")) {
+      const bool conv = d.a_mode == VDN_A_CONV3X3;
       const int fl = epi_flavour(d);
       const int cus = d.cu_hint > 0 && d.cu_hint <= 256 ? d.cu_hint : 256;
       const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
-      const int nk_total = d.ldb / 32;
-      if ((fl == VDN_STX_HALF || fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) && tiles128 * 2 <= cus && nk_total >= 64) {
+      const int nk_total = conv ? d.ldb / 32 : d.K / 32;
+      const bool fl_ok = fl == VDN_STX_HALF || (conv ? (fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) : fl == VDN_STX_RES);
+      if (fl_ok && tiles128 * 2 <= cus && nk_total >= (conv ? 64 : 32)) {
         long ks = cus / tiles128;
         ks = ks < 8 ? ks : 8;
         ks = ks < nk_total / 16 ? ks : nk_total / 16;

@@ -214,7 +214,7 @@ class Runtime:
             d.cB, d.cH, d.cW = convt["B"], convt["H"], convt["W"]
         d.zeros = self.zeros.data_ptr()
         d.cu_hint = self.cu_hint
-        if conv is not None and self.split:  # split-K scratch for low-occupancy convolutions (include/vdn.h)
+        if self.split:  # split-K scratch for launches whose tile grid covers a fraction of the chip (include/vdn.h)
             ws = self.buf("splitk_ws", (32 * 1024 * 1024,), torch.float32)
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
         self._launch(abi.lib.vdn_gemm, C.byref(d), tag=tag)
