@@ -1674,9 +1674,12 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
       const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
       const int nk_total = conv ? d.ldb / 32 : d.K / 32;
       const bool fl_ok = fl == VDN_STX_HALF || (conv ? (fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) : fl == VDN_STX_RES);
-      if (fl_ok && tiles128 * 2 <= cus && nk_total >= (conv ? 64 : 32)) {
-        long ks = cus / tiles128;
-        ks = ks < 8 ? ks : 8;
+      const char* oe = getenv("VDN_SPLITK_OCC");  // experiment knobs: occupancy threshold (percent), slice cap
+      const char* me = getenv("VDN_SPLITK_MAX");
+      const long occ = oe ? atol(oe) : 50, ks_max = me ? atol(me) : 8;
+      if (fl_ok && tiles128 * 100 <= cus * occ && nk_total >= (conv ? 64 : 32)) {
+        long ks = (cus + tiles128 - 1) / tiles128;
+        ks = ks < ks_max ? ks : ks_max;
         ks = ks < nk_total / 16 ? ks : nk_total / 16;
         const long fit = d.splitk_ws_bytes / ((long)d.M * d.N * 4);
         ks = ks < fit ? ks : fit;
