@@ -1537,7 +1537,7 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   if (!a8 && fl != VDN_STX_RES && fl != VDN_STX_HEADS) fl = d.store;
   if (d.a_mode == VDN_A_CONV3X3) {
     if (fl != VDN_STX_HALF && fl != VDN_STX_RESHALF1 && fl != VDN_STX_RESHALF2) fl = VDN_ST_PLAIN;
-  } else if (BM < 192 || fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) {
+  } else if (fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) {
     fl = d.store;
   }
   if constexpr (BM == 256 || BM == 192) {  // ping-pong 8-phase kernel (VDN_GEMM_P8=0 falls back to the lock-step one)
@@ -1588,12 +1588,12 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   } else {
     switch (fl) {
       case VDN_ST_PLAIN: VDN_LAUNCH_BIG(0, VDN_ST_PLAIN); break;
-      case VDN_STX_HALF: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_HALF); } break;
+      case VDN_STX_HALF: VDN_LAUNCH_BIG(0, VDN_STX_HALF); break;
       case VDN_ST_CONVT: VDN_LAUNCH_BIG(0, VDN_ST_CONVT); break;
       case VDN_ST_GEGLU: VDN_LAUNCH_BIG(0, VDN_ST_GEGLU); break;
-      case VDN_STX_FC1: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_FC1); } break;
-      case VDN_STX_RES: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_RES); } break;
-      case VDN_STX_HEADS: if constexpr (BM >= 192) { VDN_LAUNCH_BIG(0, VDN_STX_HEADS); } break;
+      case VDN_STX_FC1: VDN_LAUNCH_BIG(0, VDN_STX_FC1); break;
+      case VDN_STX_RES: VDN_LAUNCH_BIG(0, VDN_STX_RES); break;
+      case VDN_STX_HEADS: VDN_LAUNCH_BIG(0, VDN_STX_HEADS); break;
       default: VDN_LAUNCH_BIG(0, VDN_ST_HEADS); break;
     }
   }
@@ -1664,7 +1664,9 @@ inline int pick_bm(int M, int N, int cu_hint) {
 
 template <int DT>
 int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
-  if (d.A_lo && d.W_lo && d.N >= 192 && (long)d.M * d.N >= 256L * 1024 &&
+  // 8-wave kernels: large problems, and small ones whose deep reduction makes them split-K candidates
+  const bool deep = d.splitk_ws && (d.a_mode == VDN_A_CONV3X3 ? d.ldb : d.K) >= 2048 && (long)d.M * d.N >= 32L * 1024;
+  if (d.A_lo && d.W_lo && d.N >= 192 && ((long)d.M * d.N >= 256L * 1024 || deep) &&
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
     const char* force = getenv("VDN_GEMM_BM");
     if (d.splitk_ws && !force && !(d.N & 3) && !getenv("VDN_GEMM_NOSPLITK")) {
@@ -1694,7 +1696,8 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
     const char* mt = getenv("VDN_GEMM_MIN_TILES");  // experiment knob; 0 disables
     const long min_tiles = mt ? atol(mt) : 96;
     const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
-    const bool small = !force && min_tiles > 0 && tiles128 < min_tiles && d.a_mode != VDN_A_CONV3X3;
+    const bool small = !force && ((min_tiles > 0 && tiles128 < min_tiles && d.a_mode != VDN_A_CONV3X3) ||
+                                 (long)d.M * d.N < 256L * 1024);  // admitted only as a split-K candidate
     if (!small && (bm == 256 || bm == 192 || bm == 128)) return big_entry<DT>(d, bm, s);
   }
   if (d.A_lo && d.W_lo && (d.store == VDN_ST_HEADS || d.N > 64)) return launch_x3<DT>(d, s);
