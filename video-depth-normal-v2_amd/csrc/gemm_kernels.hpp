@@ -1238,10 +1238,15 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
   // slot, slot + G/8, ... of ITS XCD's contiguous chunk of the tile order, so the 32 workgroups of an XCD still
   // sweep consecutive tiles together; the stores of a finished tile drain while the next tile's main loop runs.
   const int ntiles = tiles_m * tiles_n;
-  const bool persistent = (int)gridDim.x < ntiles;
+  constexpr bool SPLITK = STORE == VDN_STX_SPLITK;  // grid = ksplit copies of the tile grid (see gemm_x3_big_kernel)
+  const int slice = SPLITK ? (int)blockIdx.x / ntiles : 0;
+  const bool persistent = !SPLITK && (int)gridDim.x < ntiles;
   for (int it = 0;; ++it) {
   int tile;
-  if (persistent) {
+  if constexpr (SPLITK) {
+    if (it) break;
+    tile = xcd_remap((int)blockIdx.x - slice * ntiles, ntiles);
+  } else if (persistent) {
     const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
     const int base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int idx = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
@@ -1263,6 +1268,7 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
   const int m0 = tm_i * BM, n0 = tn_i * BN;
   const int wm = wave >> 2, wn = wave & 3;
 
+  const int kt0s = SPLITK ? slice * ((((AMODE == 1 || AMODE == 2) ? p.ldb / BK3 : p.K / BK3) + p.ksplit - 1) / p.ksplit) : 0;
   // ---- DMA duty of this wave: one 16-row piece (x 2 planes) of each of the four units
   const int lr = lane >> 2;
   const int chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
@@ -1332,6 +1338,7 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
       if constexpr (CONV) {
         bool ok;
         const char* src;
+        kt += kt0s;  // absolute K step (split-K slices)
         if (p.conv_korder) {
           // (ci/64, tap, ci%64) K order: the K tile fixes one tap and one 32-channel slice for every lane, so
           // the decode is wave-uniform scalar work; per lane only a precomputed validity bit and one 64-bit
@@ -1397,7 +1404,15 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = CONV ? p.ldb / BK3 : p.K / BK3;
+  const int nk_total = CONV ? p.ldb / BK3 : p.K / BK3;
+  const int nk_slice = SPLITK ? (nk_total + p.ksplit - 1) / p.ksplit : nk_total;
+  const int kt0 = slice * nk_slice;
+  const int nk = (nk_total - kt0) < nk_slice ? (nk_total - kt0) : nk_slice;
+  if constexpr (SPLITK) {  // plain rows start at this slice's first K step (pointer-increment staging)
+    if constexpr (!CONV) { ap[0] += (size_t)kt0 * 64; ap[1] += (size_t)kt0 * 64; }
+    wp[0] += (size_t)kt0 * 64;
+    wp[1] += (size_t)kt0 * 64;
+  }
   V8 ah[TQ], al[TQ], bh[2], bl[2];
   auto read_a = [&](const char* s0, int qa) {
 #pragma unroll
@@ -1476,7 +1491,14 @@ __global__ __launch_bounds__(512) void gemm_x3_p8_kernel(const vdn_gemm_desc p) 
 #undef VDN_PHASE
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
 
-  epilogue_regs<DT, 2 * TQ, 4, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  if constexpr (SPLITK) {
+    vdn_gemm_desc q = p;
+    q.out = (float*)p.splitk_ws + (size_t)slice * p.M * p.N;
+    q.ldc = p.N;
+    epilogue_regs<DT, 2 * TQ, 4, STORE, false>(acc, q, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  } else {
+    epilogue_regs<DT, 2 * TQ, 4, STORE, vdn_pair8<STORE>>(acc, p, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  }
   }  // tile loop
 }
 
@@ -1625,10 +1647,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vdn_gemm_desc 
 template <int DT>
 int launch_splitk(const vdn_gemm_desc& d0, int ksplit, int fl, hipStream_t s) {
   vdn_gemm_desc d = d0;
-  d.ksplit = ksplit;
-  const int tiles = ((d.M + 127) / 128) * ((d.N + 255) / 256);
-  const size_t lds = 2 * (size_t)(2 * 128 * 64 + 2 * 256 * 64);
-  if (d.a_mode != VDN_A_CONV3X3) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
+  const bool p8 = ksplit < 0;  // negative: the 256 x 256 ping-pong kernel (plain A only), |ksplit| slices
+  d.ksplit = p8 ? -ksplit : ksplit;
+  const int tiles = p8 ? ((d.M + 255) / 256) * ((d.N + 255) / 256) : ((d.M + 127) / 128) * ((d.N + 255) / 256);
+  const size_t lds = p8 ? 2 * (size_t)(2 * 256 * 64 + 2 * 256 * 64) : 2 * (size_t)(2 * 128 * 64 + 2 * 256 * 64);
+  if (p8) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, 0, VDN_STX_SPLITK, 256>), dim3(tiles * d.ksplit), dim3(512), lds, s, d);
+  else if (d.a_mode != VDN_A_CONV3X3) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 0, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
   else if (d.relu_a) hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 2, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
   else hipLaunchKernelGGL((gemm_x3_big_kernel<DT, 1, 128, VDN_STX_SPLITK, true>), dim3(tiles * ksplit), dim3(512), lds, s, d);
   const size_t work = (size_t)d.M * (d.N >> 2);
@@ -1688,6 +1712,12 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
         while (ks >= 2 && (ks - 1) * ((nk_total + ks - 1) / ks) >= nk_total) --ks;  // every slice non-empty
         if (ks >= 2) return splitk_entry<DT>(d, (int)ks, fl, s);
       }
+    }
+    if (const char* pe8 = getenv("VDN_SPLITK_P8")) {  // experiment: deep residual linears on the ping-pong kernel, K split
+      const int ks = atoi(pe8);
+      if (ks >= 2 && d.splitk_ws && !force && d.a_mode == VDN_A_PLAIN && epi_flavour(d) == VDN_STX_RES && d.K >= 2048 &&
+          (long)d.M * d.N * 4 * ks <= d.splitk_ws_bytes)
+        return splitk_entry<DT>(d, -ks, VDN_STX_RES, s);
     }
     const int bm = force ? atoi(force) : pick_bm(d.M, d.N, d.cu_hint);
     // small problems (batch 1: M = 1370): a grid of 128 x 256 tiles covers a fraction of the chip; the 4-wave 128 x 128
