@@ -131,6 +131,26 @@ typedef struct vdn_gemm_desc {
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
 
+/* Process-wide kernel-selection knobs of vdn_gemm (which tile / pipeline / split-K variant a shape gets; never
+ * what is computed). Initialised ONCE, at the first use, from the environment variables named below; afterwards
+ * only vdn_gemm_set_tuning changes them (tests pin a tile with force_bm; tools run A/B experiments). Not
+ * thread-safe against concurrent launches: set before launching.                                             */
+typedef struct vdn_gemm_tuning {
+  int force_bm;     /* VDN_GEMM_BM       0 = pick_bm(); 128 | 192 | 256 force the 8-wave kernel's M tile          */
+  int p8;           /* VDN_GEMM_P8       1 = ping-pong kernel at BM 256 (default), 2 = also BM 192, 0 = never     */
+  int no_splitk;    /* VDN_GEMM_NOSPLITK 1 = never split K                                                        */
+  int no_pipe;      /* VDN_GEMM_NOPIPE   1 = lock-step loop without the phase shift                               */
+  int persist;      /* VDN_GEMM_PERSIST  1 = ping-pong kernel as 256 persistent workgroups (measured slower)      */
+  int splitk_p8;    /* VDN_SPLITK_P8     >= 2: K slices for deep residual linears on the ping-pong kernel         */
+  int cus;          /* VDN_GEMM_CUS      > 0 overrides the CU count tiles are sized for (else desc.cu_hint / 256)  */
+  int splitk_occ;   /* VDN_SPLITK_OCC    split K when the 128-row tile grid covers <= this percent of the CUs (50) */
+  int splitk_max;   /* VDN_SPLITK_MAX    most K slices (8)                                                        */
+  int min_tiles;    /* VDN_GEMM_MIN_TILES plain-A problems with fewer 128x256 tiles use the 4-wave 128x128 kernel (96) */
+  float f128, f192; /* VDN_GEMM_F128/F192 cost factors of the smaller M tiles in pick_bm (1.12, 1.04)             */
+} vdn_gemm_tuning;
+int vdn_gemm_get_tuning(vdn_gemm_tuning* out);
+int vdn_gemm_set_tuning(const vdn_gemm_tuning* in);
+
 /* LayerNorm over the last dim of [rows, C] (fp32 statistics, two-pass in registers).
  *   y = LN(x) * w + b;  y += alpha * addvec[c];  y += addtab[(row / tab_div) % tab_mod, c]
  * writes out_h (half, optional) and out_f (f32, optional).

@@ -16,3 +16,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def tune():
+    """Pin vdn_gemm's kernel selection for one test through the C-ABI (vdn_gemm_set_tuning) and restore it after:
+    `tune(force_bm=192)`. The library reads its VDN_GEMM_* environment defaults once per process, never per launch."""
+    from vdn import _abi
+    saved = _abi.get_tuning()
+
+    def _set(**kw):
+        _abi.set_tuning(**kw)
+
+    yield _set
+    _abi.restore_tuning(saved)

@@ -63,8 +63,66 @@ def test_A_vits_batch2_266():
     _stream_A("A_vits_b2_266", "vits", oracle_steps=3)
 
 
-def test_A_vitl_518():
+def test_A_vitl_518_stream_fill_and_evict():
+    """BASELINE configs[1] at batch 1: ViT-L, 8 frames on one memory bank — every depth S = 0..6, then one eviction —
+    against the fixture written by the imported reference (frames 0, 1, 6, 7 kept)."""
     _stream_A("A_vitl_518", "vitl", oracle_steps=1)
+
+
+def _lanes_against_single_lane_and_fixture(name, enc, B, monkeypatch):
+    """The dispatch bench.py times: a batch of B independent streams dealt to two HIP-stream lanes (own workspace,
+    cu_hint = 128, one shared memory-bank ring) for 8 steps — empty bank, filling, full, eviction. Every step must
+    equal the single-lane run of the same batch, and batch element 0 carries the fixture's stream, so it must also
+    match the reference fixture: lanes, batching and bank slicing change nothing."""
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    _, steps, H, W, sub, _ = [int(v) for v in g["meta"]]
+    kept = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("pre_") and not k.startswith("pre_stats"))
+    pool = inputs(steps + B - 1, H, W)  # element b sees the fixture's stream delayed by b frames
+    model = _product("A", enc)
+    runs = {}
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("VDN_STREAMS", lanes)
+        model.clear_memory()
+        outs = []
+        for t in range(steps):
+            xb = torch.stack([pool[t + b] for b in range(B)])
+            outs.append(model.forward(xb.cuda(), _pre_relu=True).cpu())
+            assert torch.isfinite(outs[-1]).all()
+        runs[lanes] = outs
+        if lanes == "2":
+            assert model._lanes is not None and len(model._lanes) == 2, "the two-lane path did not run"
+    worst_l, worst_f = 0.0, 0.0
+    for t in range(steps):
+        e = rel_l2(runs["2"][t], runs["1"][t])
+        worst_l = max(worst_l, e)
+        assert e < 3e-6, (t, e)  # same arithmetic; only the split-K slicing follows the lane's CU share
+        if t in kept:
+            for lanes in ("2", "1"):
+                ef = rel_l2(torch.relu(runs[lanes][t][0, ::sub, ::sub]), np.maximum(g[f"pre_{t}"][0], 0))
+                worst_f = max(worst_f, ef)
+                assert ef < TOL, (lanes, t, ef)
+    print(f"[{name} B={B}] two lanes vs one lane: worst step {worst_l:.2e}; element 0 vs reference fixture: worst {worst_f:.2e}")
+
+
+def test_A_vitl_batch8_two_lanes_benchmarked_dispatch(monkeypatch):
+    """BASELINE configs[1] exactly as bench.py runs it: DepthAnythingV2(vitl), batch 8, two lanes, S = 0..6 + eviction."""
+    _lanes_against_single_lane_and_fixture("A_vitl_518", "vitl", 8, monkeypatch)
+
+
+def test_A_vits_batch4_two_lanes(monkeypatch):
+    _lanes_against_single_lane_and_fixture("A_vits_518", "vits", 4, monkeypatch)
+
+
+def test_memory_bank_rejects_a_batch_change_until_cleared():
+    """One ring for the whole batch: a frame whose batch differs from the stored memories is an error, as in the
+    reference (memory_attention.py:135-137), not a silent reset."""
+    model = _product("A", "vits")
+    x = inputs(2, 266, 266)
+    model.forward(x[:1].cuda())
+    with pytest.raises(RuntimeError, match="clear_memory"):
+        model.forward(x.cuda())
+    model.clear_memory()
+    assert torch.isfinite(model.forward(x.cuda())).all()
 
 
 def _clip_B(name, enc, use_oracle):
@@ -102,6 +160,12 @@ def test_B_vits_nonsquare_short_clip():
 
 def test_B_vitl_4_frames():
     _clip_B("B_vitl_518", "vitl", use_oracle=False)
+
+
+def test_B_vitl_full_32_frame_window():
+    """BASELINE configs[2]: VideoDepthAnything(vitl) on the full 32-frame 518x518 window, against the fixture written
+    by the imported reference (frames 0, 13, 31 and every frame's mean)."""
+    _clip_B("B_vitl_518_T32", "vitl", use_oracle=False)
 
 
 def test_determinism_and_memory_reset():
@@ -237,6 +301,30 @@ def test_depth_refiner_v4_v5_against_reference_fixture(version, name):
     # two clips in one batch are independent
     both = m.forward(torch.cat([x, x * 0.5 + 100.0]).cuda()).cpu()
     assert rel_l2(both[0], g["out"]) < TOL
+
+
+def test_depth_refiner_v5_vitl_64_frames_1024():
+    """BASELINE configs[4] as the reference implements it: video_depth_model_v5 (ViT-L, num_frames = 64) on a
+    [1, 64, 1024, 1024] raw depth clip (the network itself runs at 224 x 224), against the imported reference's
+    fixture: a 16-strided sample of every refined frame plus per-frame statistics of the full maps."""
+    import vdn
+    from vdn import synth
+    from vdn.video_depth_model_v5 import VideoDepthAnything
+    g = np.load(os.path.join(GOLD, "R5_vitl_T64.npz"))
+    v, S, H, W, seed = [int(t) for t in g["meta"]]
+    sub, nf = int(g["sub"]), int(g["num_frames"])
+    m = VideoDepthAnything(num_frames=nf, **vdn.MODEL_CONFIGS["vitl"])
+    m.load_state_dict(synth_sd("R5", "vitl"), strict=True)
+    m = m.to("cuda").eval()
+    x = torch.from_numpy(synth.depth_clip(seed, S, H, W))[None]
+    out = m.forward(x.cuda())[0].cpu()
+    assert torch.isfinite(out).all()
+    e = rel_l2(out[:, ::sub, ::sub], g["out"])
+    per_frame = max(rel_l2(out[t, ::sub, ::sub], g["out"][t]) for t in range(S))
+    means = np.array([out[t].mean().item() for t in range(S)])
+    print(f"[R5_vitl_T64] refined depth vs reference fixture {e:.2e} (worst frame {per_frame:.2e})")
+    assert e < TOL and per_frame < TOL
+    assert np.allclose(means, g["out_stats"][:, 0], rtol=1e-3)
 
 
 @pytest.mark.parametrize("use_residual,input_normal", [(False, True), (True, False)])

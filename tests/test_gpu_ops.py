@@ -553,10 +553,10 @@ def test_x3_temporal_norms_upsample_headout(rt3):
 
 @pytest.mark.parametrize("bm", ["128", "192", "256"])
 @pytest.mark.parametrize("M,N,K", [(724, 1152, 384), (724, 384, 1536), (1370, 1152, 384), (2050, 256, 2304), (700, 1024, 64), (513, 200, 96)])
-def test_x3_big_tile_gemm_ragged(rt3, bm, M, N, K, monkeypatch):
+def test_x3_big_tile_gemm_ragged(rt3, bm, M, N, K, tune):
     """The 8-wave BM x 256 kernels on ragged M / N (tails in both), every BM variant forced."""
     from vdn import pack, _abi
-    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    tune(force_bm=int(bm))
     a = rnd(M, K, seed=300)
     w = rnd(N, K, seed=301, scale=1 / math.sqrt(K))
     b, g = rnd(N, seed=302), rnd(N, seed=303)
@@ -571,10 +571,10 @@ def test_x3_big_tile_gemm_ragged(rt3, bm, M, N, K, monkeypatch):
 
 
 @pytest.mark.parametrize("bm", ["128", "256"])
-def test_x3_big_tile_heads_and_conv(rt3, bm, monkeypatch):
+def test_x3_big_tile_heads_and_conv(rt3, bm, tune):
     from vdn import pack, _abi
     from vdn.runtime import ceil_to
-    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    tune(force_bm=int(bm))
     B, T, Hh = 2, 362, 6
     C = Hh * 64
     a = rnd(B * T, C, seed=310)
@@ -607,11 +607,11 @@ def test_x3_big_tile_heads_and_conv(rt3, bm, monkeypatch):
     close(out.float(), ref, 5e-6)
 
 
-def test_x3_big_tile_k_smaller_than_padded_stride_with_poisoned_neighbour(rt3, monkeypatch):
+def test_x3_big_tile_k_smaller_than_padded_stride_with_poisoned_neighbour(rt3, tune):
     """K = 96 (weights padded to 128): the A rows must not be read past K — the memory right after the
     A buffer is NaN here, which a read of columns 96..127 of the last row would pull in (0 x NaN)."""
     from vdn import pack, _abi
-    monkeypatch.setenv("VDN_GEMM_BM", "128")
+    tune(force_bm=128)
     M, N, K = 722, 384, 96
     a = rnd(M, K, seed=320)
     w = rnd(N, K, seed=321, scale=1 / math.sqrt(K))
@@ -628,13 +628,13 @@ def test_x3_big_tile_k_smaller_than_padded_stride_with_poisoned_neighbour(rt3, m
 
 @pytest.mark.parametrize("p8,bm", [("1", "256"), ("2", "192")])
 @pytest.mark.parametrize("K", [32, 64, 160])
-def test_x3_pingpong_gemm_short_k_and_repeatability(rt3, p8, bm, K, monkeypatch):
+def test_x3_pingpong_gemm_short_k_and_repeatability(rt3, p8, bm, K, tune):
     """The 8-phase ping-pong kernel with 1, 2 and 5 K tiles (prologue only / drain counts 2,0 / steady state),
     ragged M and N, run 8 times: every run must be bitwise identical (a counted-vmcnt or barrier-parity
     mistake shows up as rare differing tiles long before it shows up as a wrong mean)."""
     from vdn import pack, _abi
-    monkeypatch.setenv("VDN_GEMM_BM", bm)
-    monkeypatch.setenv("VDN_GEMM_P8", p8)
+    tune(force_bm=int(bm))
+    tune(p8=int(p8))
     M, N = 1370 + 77, 1024 + 200
     a = rnd(M, K, seed=330)
     w = rnd(N, K, seed=331, scale=1 / math.sqrt(K))
@@ -652,11 +652,11 @@ def test_x3_pingpong_gemm_short_k_and_repeatability(rt3, p8, bm, K, monkeypatch)
 
 @pytest.mark.parametrize("bm", ["128", "192", "256"])
 @pytest.mark.parametrize("two", [False, True])
-def test_x3_conv_residual_plane_flavours(rt3, bm, two, monkeypatch):
+def test_x3_conv_residual_plane_flavours(rt3, bm, two, tune):
     """3x3 conv + bias + one / two split-half residuals -> split-half output (the ResidualConvUnit's second conv:
     the straight-line epilogue flavours) on every 8-wave tile height, against fp64."""
     from vdn import pack
-    monkeypatch.setenv("VDN_GEMM_BM", bm)
+    tune(force_bm=int(bm))
     B, H, W, Ci, Co = 2, 41, 37, 64, 256
     x = rnd(B, H, W, Ci, seed=340)
     w = rnd(Co, Ci, 3, 3, seed=341, scale=1 / math.sqrt(9 * Ci))
@@ -783,7 +783,7 @@ def test_cu_hint_only_changes_the_tiling(rt3):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,two,relu_a", [(1, 19, 19, 256, 256, False, False), (2, 19, 19, 1024, 256, False, False),
                                                     (1, 37, 37, 256, 256, True, True), (4, 19, 19, 512, 1024, False, False)])
-def test_x3_conv_split_k_matches_single_pass(rt3, B, H, W, Ci, Co, two, relu_a, monkeypatch):
+def test_x3_conv_split_k_matches_single_pass(rt3, B, H, W, Ci, Co, two, relu_a, tune):
     """Low-resolution convolutions with deep reductions run as K slices + an ordered reduce (vdn.h: splitk_ws):
     against fp64 and against the unsplit kernel (VDN_GEMM_NOSPLITK), bitwise repeatable."""
     from vdn import pack, _abi
@@ -812,13 +812,13 @@ def test_x3_conv_split_k_matches_single_pass(rt3, B, H, W, Ci, Co, two, relu_a, 
     first = (out.hi.clone(), out.lo.clone())
     rt3.gemm(xa, wp, B * H * W, Co, 9 * Ci, out=out, **kw)
     assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
-    monkeypatch.setenv("VDN_GEMM_NOSPLITK", "1")
+    tune(no_splitk=1)
     rt3.gemm(xa, wp, B * H * W, Co, 9 * Ci, out=out, **kw)
     close(out.float(), first[0].float() + first[1].float(), 3e-6)
 
 
 @pytest.mark.parametrize("M,N,K", [(1370, 1024, 4096), (1369, 1024, 1024), (361, 256, 2048)])
-def test_x3_plain_split_k_residual_and_planes(rt3, M, N, K, monkeypatch):
+def test_x3_plain_split_k_residual_and_planes(rt3, M, N, K, tune):
     """Small-M linears (batch-1 encoder: 44 tiles of 128x256) run as K slices + ordered reduce: the in-place
     LayerScale residual update and a plane-output projection, against fp64 and the unsplit kernel."""
     from vdn import pack
@@ -837,7 +837,7 @@ def test_x3_plain_split_k_residual_and_planes(rt3, M, N, K, monkeypatch):
     first = (oh.hi.clone(), oh.lo.clone())
     rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV))
     assert torch.equal(oh.hi, first[0]) and torch.equal(oh.lo, first[1])
-    monkeypatch.setenv("VDN_GEMM_NOSPLITK", "1")
+    tune(no_splitk=1)
     xd2 = x.clone().to(DEV)
     rt3.gemm(A, W, M, N, K, out=xd2, bias=b.to(DEV), gamma=g.to(DEV), res1=xd2)
     close(xd2, xd, 3e-6)

@@ -71,7 +71,7 @@ def test_oracle_B_vits_nonsquare():
 
 
 def test_oracle_A_vitl():
-    _run_A("A_vitl_518", "vitl", check_steps=[0])
+    _run_A("A_vitl_518", "vitl", check_steps=[0, 1])  # S = 0 and the first cross-attention over a stored frame
 
 
 def test_oracle_host_pieces():

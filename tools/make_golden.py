@@ -197,7 +197,7 @@ def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str):
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
-def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str):
+def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str, num_frames: int = 32, sub: int = 1):
     """models/video_depth_model_v{4,5}.VideoDepthAnything on a synthetic depth clip."""
     import importlib
     from vdn import synth
@@ -211,7 +211,7 @@ def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str):
     spec.loader.exec_module(mod)
     cfg = O.MODEL_CONFIGS[enc]
     torch.manual_seed(0)
-    model = mod.VideoDepthAnything(**cfg).eval()
+    model = mod.VideoDepthAnything(num_frames=num_frames, **cfg).eval()
     sd, shapes = load_synth(model)
     with open(os.path.join(GOLD, f"schema_R{version}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
@@ -227,8 +227,12 @@ def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str):
     print(f"[R{version} {name}] S={S} {H}x{W} ref {time.time() - t0:.1f}s out mean {ref.mean():.1f} std {ref.std():.1f} "
           f"scale {tr['scale'].numpy().round(4)} net_depth mean {tr['net_depth'].mean():.4f} | oracle rel err {e:.2e}")
     assert e <= 1e-5
-    out = {"meta": np.array([version, S, H, W, SEED]), "out": ref[0].numpy(), "median": tr["median"].numpy(),
-           "scale": tr["scale"].numpy(), "net_depth": tr["net_depth"][0].numpy()}
+    out = {"meta": np.array([version, S, H, W, SEED]), "median": tr["median"].numpy(), "scale": tr["scale"].numpy()}
+    if sub == 1:
+        out.update(out=ref[0].numpy(), net_depth=tr["net_depth"][0].numpy())
+    else:  # large clips: a strided sample of every frame + per-frame statistics of the full maps
+        out.update(out=ref[0, :, ::sub, ::sub].numpy(), sub=np.array(sub), num_frames=np.array(num_frames),
+                   out_stats=np.stack([stats(ref[0, t]) for t in range(S)]))
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
@@ -376,8 +380,13 @@ JOBS = {
     "B_vits_518": lambda: gen_B("vits", 518, 518, 32, [0, 13, 31], 2, "B_vits_518"),
     "B_vits_392x518": lambda: gen_B("vits", 392, 518, 8, [0, 7], 2, "B_vits_392x518"),
     "S_vits_266": lambda: gen_stream("vits", 266, 266, 14, [0, 1, 11, 13], "S_vits_266"),
-    "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 2, [0, 1], 4, "A_vitl_518"),
+    # BASELINE configs[1]: ViT-L stream through every memory depth S = 0..6 and one eviction
+    "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 8, [0, 1, 6, 7], 4, "A_vitl_518"),
     "B_vitl_518": lambda: gen_B("vitl", 518, 518, 4, [0, 3], 4, "B_vitl_518"),
+    # BASELINE configs[2]: the full 32-frame ViT-L window
+    "B_vitl_518_T32": lambda: gen_B("vitl", 518, 518, 32, [0, 13, 31], 4, "B_vitl_518_T32"),
+    # BASELINE configs[4]: v5 refiner, ViT-L, num_frames = 64 on a [1, 64, 1024, 1024] clip (the network runs at 224 x 224)
+    "R5_vitl_T64": lambda: gen_refiner(5, "vitl", 64, 1024, 1024, "R5_vitl_T64", num_frames=64, sub=16),
     "R5_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5_vits"),
     "R4_vits": lambda: gen_refiner(4, "vits", 3, 126, 168, "R4_vits"),
 }

@@ -1,7 +1,7 @@
 import os, sys, math, torch
-sys.path.insert(0, "/root/repo/video-depth-normal-v2_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-depth-normal-v2_amd"))
 from vdn.runtime import Runtime
-from vdn import pack
+from vdn import pack, _abi
 rt = Runtime(torch.device("cuda:0"), torch.float16, split=True)
 torch.manual_seed(0)
 for (M, N, K) in ((5480, 1024, 4096), (10960, 1024, 4096), (1370, 1024, 2048)):
@@ -10,7 +10,7 @@ for (M, N, K) in ((5480, 1024, 4096), (10960, 1024, 4096), (1370, 1024, 2048)):
     ref = (x.double() + (a.double() @ w.double().t() + b.double()) * g.double()).float()
     A, W = rt.to_half(a), pack.linear(w, rt.prec)
     for ks in ("0", "2", "3"):
-        os.environ["VDN_SPLITK_P8"] = ks
+        _abi.set_tuning(splitk_p8=int(ks))
         xd = x.clone()
         rt.gemm(A, W, M, N, K, out=xd, bias=b, gamma=g, res1=xd)
         err = ((xd.double() - ref.double()).norm() / ref.double().norm()).item()

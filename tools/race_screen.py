@@ -13,7 +13,7 @@ rt = Runtime(torch.device("cuda:0"), torch.float16, split=True)
 torch.manual_seed(0)
 bad = 0
 for bm in ("256", "192", "128"):
-    os.environ["VDN_GEMM_BM"] = bm
+    _abi.set_tuning(force_bm=int(bm))
     for (M, N, K) in ((10960, 4096, 1024), (5480, 1024, 4096), (1370, 3072, 1024), (2050, 512, 96)):
         a = rt.to_half(torch.randn(M, K, device="cuda"))
         w = pack._pad_k(torch.randn(N, K, device="cuda") / math.sqrt(K), rt.prec)
@@ -27,7 +27,7 @@ for bm in ("256", "192", "128"):
             diff += int(not (torch.equal(out.hi, h0) and torch.equal(out.lo, l0)))
         bad += diff
         print(f"gemm BM={bm} M={M} N={N} K={K}: {diff} of {reps} runs differ", flush=True)
-os.environ.pop("VDN_GEMM_BM")
+_abi.set_tuning(force_bm=0)
 for (B, H, nq, nk) in ((8, 16, 1370, 1370), (4, 16, 1369, 8214), (2, 6, 150, 200), (1, 16, 361, 1369)):
     qp, kp = ceil_to(nq, 64), ceil_to(nk, 64)
     q = rt.to_half(torch.randn(B * H, qp, 64, device="cuda"))

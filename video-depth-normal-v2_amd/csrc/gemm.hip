@@ -1,10 +1,53 @@
 // vdn_gemm: argument validation + dispatch. Kernels live in gemm_kernels.hpp and are instantiated
 // per operand dtype in gemm_small_{f16,bf16}.hip / gemm_big_{f16,bf16}.hip (parallel compilation).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace vdn_gemm_impl {
 int launch_f16(const vdn_gemm_desc& d, hipStream_t s);
 int launch_bf16(const vdn_gemm_desc& d, hipStream_t s);
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static float env_float(const char* name, float dflt) {
+  const char* e = getenv(name);
+  return e ? (float)atof(e) : dflt;
+}
+static vdn_gemm_tuning& tuning_rw() {
+  static vdn_gemm_tuning t = [] {  // the environment is read here, once per process
+    vdn_gemm_tuning v;
+    v.force_bm = env_int("VDN_GEMM_BM", 0);
+    v.p8 = env_int("VDN_GEMM_P8", 1);
+    v.no_splitk = getenv("VDN_GEMM_NOSPLITK") != nullptr;
+    v.no_pipe = getenv("VDN_GEMM_NOPIPE") != nullptr;
+    v.persist = env_int("VDN_GEMM_PERSIST", 0);
+    v.splitk_p8 = env_int("VDN_SPLITK_P8", 0);
+    v.cus = env_int("VDN_GEMM_CUS", 0);
+    v.splitk_occ = env_int("VDN_SPLITK_OCC", 50);
+    v.splitk_max = env_int("VDN_SPLITK_MAX", 8);
+    v.min_tiles = env_int("VDN_GEMM_MIN_TILES", 96);
+    v.f128 = env_float("VDN_GEMM_F128", 1.12f);
+    v.f192 = env_float("VDN_GEMM_F192", 1.04f);
+    return v;
+  }();
+  return t;
+}
+const vdn_gemm_tuning& tuning() { return tuning_rw(); }
+}
+
+extern "C" int vdn_gemm_get_tuning(vdn_gemm_tuning* out) {
+  if (!out) return VDN_EINVAL;
+  *out = vdn_gemm_impl::tuning_rw();
+  return VDN_OK;
+}
+extern "C" int vdn_gemm_set_tuning(const vdn_gemm_tuning* in) {
+  if (!in) return VDN_EINVAL;
+  if (in->force_bm != 0 && in->force_bm != 128 && in->force_bm != 192 && in->force_bm != 256) return VDN_EINVAL;
+  if (in->splitk_occ < 0 || in->splitk_max < 0 || in->min_tiles < 0 || in->cus < 0 || in->cus > 256) return VDN_EINVAL;
+  vdn_gemm_impl::tuning_rw() = *in;
+  return VDN_OK;
 }
 
 extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {

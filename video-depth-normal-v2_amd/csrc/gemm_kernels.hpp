@@ -20,6 +20,10 @@
 
 namespace vdn_gemm_impl {
 
+// Process-wide kernel-selection knobs (include/vdn.h: vdn_gemm_tuning). Read from VDN_GEMM_* / VDN_SPLITK_* ONCE, at
+// the first launch; tests and tools change them through vdn_gemm_set_tuning(), never through the environment per launch.
+const vdn_gemm_tuning& tuning();  // gemm.hip
+
 constexpr int BK = 64;
 
 // ---------------------------------------------------------------------------------------------
@@ -120,7 +124,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     if constexpr (STORE == VDN_STX_HALF) {
       const float floor_v = p.act == VDN_ACT_RELU ? 0.f : -INFINITY;  // branch-free optional ReLU
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], floor_v);
+      for (int e = 0; e < 4; ++e) a[e] = (a[e] < floor_v) ? floor_v : a[e];  // NaN passes through (fmaxf would hide it)
     } else {
       const size_t r1 = (size_t)m * p.ldr1 + n;
       const typename H::V4 rh = *(const typename H::V4*)((const T*)p.res1 + r1), rl = *(const typename H::V4*)((const T*)p.res1_lo + r1);
@@ -179,9 +183,6 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     }
     return;
   }
-#if defined(VDN_ABLATE) && (VDN_ABLATE & 8)
-  if (p.M > 0) { if (a[0] + a[1] + a[2] + a[3] == 123.456f) *(float*)p.out = 0.f; return; }  // no math, no stores
-#endif
   if constexpr (STORE == VDN_ST_PLAIN || STORE == VDN_ST_CONVT) {
     a += bias_a;
     if (p.rowadd) a += p.rowadd[m];
@@ -189,7 +190,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
       a = gelu4(a);
     } else if (p.act == VDN_ACT_RELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+      for (int e = 0; e < 4; ++e) a[e] = (a[e] < 0.f) ? 0.f : a[e];
     }
     a *= gam;
     if (p.tab) a += *(const f32x4*)(p.tab + (size_t)(m % p.tab_mod + p.tab_off) * p.N + n);
@@ -212,9 +213,6 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     } else {
       o = (size_t)(p.row_group > 0 ? m + (m / p.row_group + 1) * p.row_skip : m) * p.ldc + n;
     }
-#if defined(VDN_ABLATE) && (VDN_ABLATE & 16)
-    if (p.M > 0) { if (a[0] + a[1] + a[2] + a[3] == 123.456f) *(float*)p.out = 0.f; return; }  // math, no stores
-#endif
     if (p.out_dt == VDN_F32) {
       *(f32x4*)((float*)p.out + o) = a;
     } else if (p.out_lo) {
@@ -222,9 +220,6 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
 #pragma unroll
       for (int e = 0; e < 4; ++e) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
       *(typename H::V4*)((T*)p.out + o) = h;
-#if defined(VDN_ABLATE) && (VDN_ABLATE & 32)
-      if (l[0] + l[1] == (T)123.f)  // hi plane only
-#endif
       *(typename H::V4*)((T*)p.out_lo + o) = l;
     } else {
       typename H::V4 h = {(T)a[0], (T)a[1], (T)a[2], (T)a[3]};
@@ -333,7 +328,7 @@ __device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x
   } else if constexpr (STORE == VDN_STX_HALF) {
     const float floor_v = p.act == VDN_ACT_RELU ? 0.f : -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], floor_v);
+    for (int e = 0; e < 8; ++e) a[e] = (a[e] < floor_v) ? floor_v : a[e];  // NaN passes through
   } else if constexpr (STORE == VDN_STX_RESHALF1 || STORE == VDN_STX_RESHALF2) {
     const size_t r1 = (size_t)m * p.ldr1 + n;
     const V8 rh = *(const V8*)((const T*)p.res1 + r1), rl = *(const V8*)((const T*)p.res1_lo + r1);
@@ -436,36 +431,6 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[TM][TN], const vdn_ge
     for (int j = 0; j < TN; ++j)
       emit4<DT, STORE>(p, mw + i * 16 + fr, nw + j * 16 + fq * 4, acc[i][j], acc[i][j + 1 < TN ? j + 1 : j], bias4[j],
                        bias4[j + 1 < TN ? j + 1 : j], gam4[j]);
-}
-
-// Epilogue through a wave-private LDS transpose (8-wave kernels, wave tile 16 TM x 64): each 16-row slab of
-// the wave's tile is written to LDS in the accumulator layout and read back so that 16 consecutive lanes
-// own one ROW's 64 columns: a store instruction then covers 4 rows x 256 contiguous bytes (f32) or
-// 128 bytes per plane (half) instead of 16 rows x 64/32 bytes. No block barrier: the region is private
-// to the wave and a wave's LDS operations execute in order.
-template <int DT, int TM, int STORE>
-__device__ __forceinline__ void epilogue_wave_lds(f32x4 (&acc)[TM][4], const vdn_gemm_desc& p, float* wl, int mw, int nw,
-                                                  int lane) {
-  constexpr int LDW = 68;  // padded row (floats)
-  const int fr = lane & 15, fq = lane >> 4;
-  const int rr = lane >> 4, cc = (lane & 15) * 4;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *(f32x4*)(wl + fr * LDW + j * 16 + fq * 4) = acc[i][j];
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int row = ps * 4 + rr;
-      const f32x4 a = *(const f32x4*)(wl + row * LDW + cc);
-      f32x4 b = a;
-      if constexpr (STORE == VDN_ST_GEGLU || STORE == VDN_ST_HEADS) b = *(const f32x4*)(wl + row * LDW + ((cc + 16) & 63));
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, o4 = {1.f, 1.f, 1.f, 1.f};
-      const bool okc = nw + cc < p.N;
-      emit4<DT, STORE>(p, mw + i * 16 + row, nw + cc, a, b, (p.bias && okc) ? *(const f32x4*)(p.bias + nw + cc) : z4,
-                       (p.bias && nw + cc + 16 < p.N) ? *(const f32x4*)(p.bias + nw + cc + 16) : z4,
-                       (p.gamma && okc) ? *(const f32x4*)(p.gamma + nw + cc) : o4);
-    }
-  }
 }
 
 template <int DT, int TM, int TN>
@@ -1015,13 +980,6 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
     for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#if VDN_ABLATE & 64
-  f32x16 acc32[TMW];
-#pragma unroll
-  for (int i = 0; i < TMW; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
-#endif
   // plain rows advance by pointer increments with no K-tail select: stop at K (a multiple of 32 on this
   // path), NOT at the padded weight stride — reading A columns K..ldb would run into the next row and,
   // on the last row, past the buffer (0 x NaN = NaN even though the padded weights are zero).
@@ -1032,26 +990,15 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
   }
 
   // one K step on stage `cur`; STAGED: the next stage's DMA is issued inside the step
-#ifndef VDN_ABLATE
-#define VDN_ABLATE 0  // tools/gemm_ablate.sh only: 1 = no DMA in the loop, 2 = no LDS reads in the loop, 4 = no MFMA
-#endif
-#if VDN_ABLATE & 2
-  V8 bh[TNW], bl[TNW], ah[2][HALF], al[2][HALF];
-#endif
   auto step = [&](int kt, auto staged) {
     constexpr bool STAGED = decltype(staged)::value;
     const int cur = kt & 1;
-    if constexpr (STAGED && !(VDN_ABLATE & 1)) {
+    if constexpr (STAGED) {
       if constexpr (CONV) stage(cur ^ 1, kt + 1); else stage_plain(cur ^ 1);
     }
     const char* s0 = smem + cur * STAGE;
-#if VDN_ABLATE & 2
-    if (kt == 0) {
-#else
     V8 bh[TNW], bl[TNW];
     V8 ah[2][HALF], al[2][HALF];
-    {
-#endif
 #pragma unroll
     for (int t = 0; t < TNW; ++t) {
       bh[t] = *(const V8*)(s0 + b_off[t]);
@@ -1065,24 +1012,6 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
         al[hf][t] = *(const V8*)(s0 + A_TILE + a_off[hf * HALF + t]);
         if constexpr (RELU_A) { ah[hf][t] = relu8(ah[hf][t]); al[hf][t] = relu8(al[hf][t]); }
       }
-    }
-#if VDN_ABLATE & 64
-    // timing experiment only (results meaningless): the same fragments through half as many 32x32x16 MFMAs
-    // (32 pipe cycles, 8 issue cycles each) instead of 16x16x32 (16 pipe / 8 issue)
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int i = 0; i < HALF; ++i)
-#pragma unroll
-        for (int j = 0; j < TNW; j += 2) {
-          f32x16& c = acc32[((hf * HALF + i) >> 1) * 2 + (j >> 1)];
-          c = H::mfma32(bh[j], al[hf][i], c);
-          c = H::mfma32(bl[j + 1], ah[hf][i], c);
-          c = H::mfma32(bh[j + 1], ah[hf][i], c);
-        }
-    stage_barrier();
-    return;
-#endif
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -1090,13 +1019,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
           f32x4 c = acc[hf * HALF + i][j];
-#if VDN_ABLATE & 4
-          c[0] += (float)bh[j][0] * (float)al[hf][i][0] + (float)bl[j][1] * (float)ah[hf][i][1];
-#else
           c = H::mfma16(bh[j], al[hf][i], c);
           c = H::mfma16(bl[j], ah[hf][i], c);
           c = H::mfma16(bh[j], ah[hf][i], c);
-#endif
           acc[hf * HALF + i][j] = c;
         }
     stage_barrier();
@@ -1173,16 +1098,6 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const vdn_gemm_desc p)
     stage_barrier();
   }
 
-  // (epilogue_wave_lds — row-contiguous stores through a wave-private LDS transpose — measured 8 % SLOWER on
-  //  the whole forward in a same-box A/B although faster on isolated plain-store GEMMs; kept for reference)
-#if VDN_ABLATE & 64
-#pragma unroll
-  for (int i = 0; i < TMW; ++i)
-#pragma unroll
-    for (int j = 0; j < TNW; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] += acc32[(i >> 1) * 2 + (j >> 1)][(i & 1) * 8 + (j & 1) * 4 + e];
-#endif
   if constexpr (STORE == VDN_STX_SPLITK) {
     vdn_gemm_desc q = p;
     q.out = (float*)p.splitk_ws + (size_t)slice * p.M * p.N;
@@ -1539,7 +1454,7 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + 255) / 256);
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * 256 * 64);
   const dim3 g(tiles), b(512);
-  const bool no_pipe = getenv("VDN_GEMM_NOPIPE") != nullptr;
+  const bool no_pipe = tuning().no_pipe != 0;
   constexpr bool CAN_PIPE = BM <= 192;  // BM = 256 has no registers for the second W fragment set
   const bool pipe = CAN_PIPE && !no_pipe;
 #define VDN_LAUNCH_BIG(AM, ST)                                                                          \
@@ -1566,11 +1481,8 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     // measured (tools/gemm_bench.py): the ping-pong loop runs at 97 % of the clock-limited MFMA rate at BM 256
     // (24 MFMAs cover a load segment) but not at BM 192 (18 do not), where the lock-step PIPE loop is as fast:
     // default = BM 256 only; VDN_GEMM_P8=2 also BM 192, =0 never.
-    const char* p8e = getenv("VDN_GEMM_P8");  // read per launch: tests flip it
-    const int p8 = p8e ? atoi(p8e) : 1;
-    if (p8 >= (BM == 256 ? 1 : 2)) {
-      const char* pe = getenv("VDN_GEMM_PERSIST");  // experiment: 256 persistent workgroups
-      const dim3 g8 = (pe && atoi(pe) != 0 && tiles > 256) ? dim3(256) : g;
+    if (tuning().p8 >= (BM == 256 ? 1 : 2)) {
+      const dim3 g8 = (tuning().persist != 0 && tiles > 256) ? dim3(256) : g;  // experiment: 256 persistent workgroups
 #define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g8, b, lds, s, d)
       if (d.a_mode == VDN_A_CONV3X3) {
 #define VDN_CONV_P8(ST) do { if (d.relu_a) VDN_LAUNCH_P8(2, ST); else VDN_LAUNCH_P8(1, ST); } while (0)
@@ -1671,16 +1583,13 @@ template <int DT> int splitk_entry(const vdn_gemm_desc& d, int ksplit, int fl, h
 // Pick the M tile that wastes the fewest CU-rounds: cost = rounds(256 CUs) * BM, padded work included.
 inline int pick_bm(int M, int N, int cu_hint) {
   const int tn = (N + 255) / 256;
-  const char* ce = getenv("VDN_GEMM_CUS");  // experiments only
-  const int cus = ce ? atoi(ce) : (cu_hint > 0 && cu_hint <= 256 ? cu_hint : 256);  // CUs one launch can count on
+  const int cus = tuning().cus > 0 ? tuning().cus : (cu_hint > 0 && cu_hint <= 256 ? cu_hint : 256);  // CUs one launch can count on
   int best = 0;
   double best_cost = 1e30;
   for (int bm : {256, 192, 128}) {
     const long tiles = (long)((M + bm - 1) / bm) * tn;
     const long rounds = (tiles + cus - 1) / cus;
-    static const double f128 = getenv("VDN_GEMM_F128") ? atof(getenv("VDN_GEMM_F128")) : 1.12;
-    static const double f192 = getenv("VDN_GEMM_F192") ? atof(getenv("VDN_GEMM_F192")) : 1.04;
-    const double cost = (double)rounds * bm * (bm == 128 ? f128 : (bm == 192 ? f192 : 1.0));  // smaller tiles feed worse
+    const double cost = (double)rounds * bm * (bm == 128 ? tuning().f128 : (bm == 192 ? tuning().f192 : 1.0));  // smaller tiles feed worse
     if (cost < best_cost) { best_cost = cost; best = bm; }
   }
   return best;
@@ -1692,17 +1601,16 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   const bool deep = d.splitk_ws && (d.a_mode == VDN_A_CONV3X3 ? d.ldb : d.K) >= 2048 && (long)d.M * d.N >= 32L * 1024;
   if (d.A_lo && d.W_lo && d.N >= 192 && ((long)d.M * d.N >= 256L * 1024 || deep) &&
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
-    const char* force = getenv("VDN_GEMM_BM");
-    if (d.splitk_ws && !force && !(d.N & 3) && !getenv("VDN_GEMM_NOSPLITK")) {
+    const vdn_gemm_tuning& tu = tuning();
+    const int force = tu.force_bm;
+    if (d.splitk_ws && !force && !(d.N & 3) && !tu.no_splitk) {
       const bool conv = d.a_mode == VDN_A_CONV3X3;
       const int fl = epi_flavour(d);
       const int cus = d.cu_hint > 0 && d.cu_hint <= 256 ? d.cu_hint : 256;
       const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
       const int nk_total = conv ? d.ldb / 32 : d.K / 32;
       const bool fl_ok = fl == VDN_STX_HALF || (conv ? (fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) : fl == VDN_STX_RES);
-      const char* oe = getenv("VDN_SPLITK_OCC");  // experiment knobs: occupancy threshold (percent), slice cap
-      const char* me = getenv("VDN_SPLITK_MAX");
-      const long occ = oe ? atol(oe) : 50, ks_max = me ? atol(me) : 8;
+      const long occ = tu.splitk_occ, ks_max = tu.splitk_max;  // occupancy threshold (percent), slice cap
       if (fl_ok && tiles128 * 100 <= cus * occ && nk_total >= (conv ? 64 : 32)) {
         long ks = (cus + tiles128 - 1) / tiles128;
         ks = ks < ks_max ? ks : ks_max;
@@ -1713,18 +1621,17 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
         if (ks >= 2) return splitk_entry<DT>(d, (int)ks, fl, s);
       }
     }
-    if (const char* pe8 = getenv("VDN_SPLITK_P8")) {  // experiment: deep residual linears on the ping-pong kernel, K split
-      const int ks = atoi(pe8);
+    {  // experiment (measured neutral): deep residual linears on the ping-pong kernel, K split
+      const int ks = tu.splitk_p8;
       if (ks >= 2 && d.splitk_ws && !force && d.a_mode == VDN_A_PLAIN && epi_flavour(d) == VDN_STX_RES && d.K >= 2048 &&
           (long)d.M * d.N * 4 * ks <= d.splitk_ws_bytes)
         return splitk_entry<DT>(d, -ks, VDN_STX_RES, s);
     }
-    const int bm = force ? atoi(force) : pick_bm(d.M, d.N, d.cu_hint);
+    const int bm = force ? force : pick_bm(d.M, d.N, d.cu_hint);
     // small problems (batch 1: M = 1370): a grid of 128 x 256 tiles covers a fraction of the chip; the 4-wave 128 x 128
     // kernel launches twice the workgroups (two per CU) with half the K-loop work each
     // (batch 1: 15.9 -> 14.8 ms per frame, batch 2: 18.4 -> 17.3 ms with the threshold at 96 tiles)
-    const char* mt = getenv("VDN_GEMM_MIN_TILES");  // experiment knob; 0 disables
-    const long min_tiles = mt ? atol(mt) : 96;
+    const long min_tiles = tu.min_tiles;  // 0 disables
     const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 255) / 256);
     const bool small = !force && ((min_tiles > 0 && tiles128 < min_tiles && d.a_mode != VDN_A_CONV3X3) ||
                                  (long)d.M * d.N < 256L * 1024);  // admitted only as a split-K candidate

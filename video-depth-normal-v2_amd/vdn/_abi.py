@@ -18,7 +18,7 @@ i32, vp, fp = C.c_int32, C.c_void_p, C.c_void_p
 
 class GemmDesc(C.Structure):
     """Mirror of vdn_gemm_desc (include/vdn.h) — field order and types must match exactly;
-    tests/test_abi.py checks sizeof/offsetof against the library's own probes."""
+    the layout is checked against the library's own sizeof/offsetof probes at import (bottom of this file) and in tests/test_host.py."""
     _fields_ = [
         ("dt", i32), ("M", i32), ("N", i32), ("K", i32),
         ("A", vp), ("a_mode", i32), ("lda", i32), ("relu_a", i32),
@@ -36,6 +36,13 @@ class GemmDesc(C.Structure):
         ("conv_korder", i32), ("cu_hint", i32),
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("ksplit", i32),
     ]
+
+
+class GemmTuning(C.Structure):
+    """Mirror of vdn_gemm_tuning (include/vdn.h): process-wide kernel-selection knobs of vdn_gemm."""
+    _fields_ = [("force_bm", i32), ("p8", i32), ("no_splitk", i32), ("no_pipe", i32), ("persist", i32), ("splitk_p8", i32),
+                ("cus", i32), ("splitk_occ", i32), ("splitk_max", i32), ("min_tiles", i32), ("f128", C.c_float),
+                ("f192", C.c_float)]
 
 
 class VdnError(RuntimeError):
@@ -57,6 +64,8 @@ lib = _load()
 
 EXPORTS = {
     "vdn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "vdn_gemm_get_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
+    "vdn_gemm_set_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
     "vdn_layernorm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_float, fp, C.c_int, C.c_int,
                                 C.c_int, vp, vp, C.c_int, fp, vp]),
     "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -100,6 +109,27 @@ for _name, (_res, _args) in EXPORTS.items():
 if (lib.vdn_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.vdn_offsetof_gemm_zeros() != GemmDesc.zeros.offset
         or lib.vdn_offsetof_gemm_res2_lo() != GemmDesc.res2_lo.offset):
     raise ImportError("vdn_gemm_desc layout mismatch between include/vdn.h and vdn/_abi.py — rebuild the library")
+
+
+def get_tuning() -> GemmTuning:
+    t = GemmTuning()
+    check(lib.vdn_gemm_get_tuning(C.byref(t)), "vdn_gemm_get_tuning")
+    return t
+
+
+def set_tuning(**kw) -> GemmTuning:
+    """Change some vdn_gemm_tuning fields; returns the previous settings (restore with restore_tuning)."""
+    old, new = get_tuning(), get_tuning()
+    for k, v in kw.items():
+        if not hasattr(new, k):
+            raise AttributeError(k)
+        setattr(new, k, v)
+    check(lib.vdn_gemm_set_tuning(C.byref(new)), "vdn_gemm_set_tuning")
+    return old
+
+
+def restore_tuning(t: GemmTuning):
+    check(lib.vdn_gemm_set_tuning(C.byref(t)), "vdn_gemm_set_tuning")
 
 
 def check(rc: int, what: str):

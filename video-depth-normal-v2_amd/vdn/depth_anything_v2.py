@@ -105,10 +105,11 @@ class DepthAnythingV2(_EngineOwner):
         return self._eng
 
     def _stream_lanes(self, n: int):
-        """`n` independent execution lanes = HIP stream + own workspace arena + own memory-bank state, all
-        sharing the packed weights. The batch elements of path A are independent video streams, so the
-        batch is dealt to the lanes and their kernels interleave on the GPU: one lane's epilogues and
-        tile-quantisation tails overlap the other's main loops (measured +6 % at batch 8, 2 lanes)."""
+        """`n` independent execution lanes = HIP stream + own workspace arena, all sharing the packed weights and
+        ONE memory-bank ring (lane i owns batch rows [i B/n, (i+1) B/n) of it, MemoryEngine.lane). The batch elements
+        of path A are independent video streams, so the batch is dealt to the lanes and their kernels interleave on
+        the GPU: one lane's epilogues and tile-quantisation tails overlap the other's main loops (measured +6 % at
+        batch 8, 2 lanes)."""
         import copy
         e = self._engines()
         if self._lanes is None or len(self._lanes) != n:
@@ -117,18 +118,16 @@ class DepthAnythingV2(_EngineOwner):
                 rt = e["rt"] if i == 0 else Runtime(e["rt"].device, e["rt"].half, e["rt"].split)
                 enc, mem, head = (copy.copy(e[k]) for k in ("enc", "mem", "head"))
                 enc.rt = mem.rt = head.rt = rt
-                if i > 0:  # per-lane state and per-lane lazily built tables (built on the lane's own stream)
-                    mem.count, mem._shape, mem._rope, enc._pos_cache = 0, None, {}, {}
-                lanes.append(dict(rt=rt, enc=enc, mem=(e["mem"] if i == 0 else mem), head=head,
-                                  stream=torch.cuda.Stream(device=rt.device)))
+                mem.lane, mem._nomem = (i, n), {}   # bank state, ring and RoPE table stay shared (built in prepare())
+                if i > 0:  # lazily built per-lane tables are built on the lane's own stream
+                    enc._pos_cache = {}
+                lanes.append(dict(rt=rt, enc=enc, mem=mem, head=head, stream=torch.cuda.Stream(device=rt.device)))
             self._lanes = lanes
         return self._lanes
 
     def clear_memory(self):
         if self._eng is not None:
             self._eng["mem"].clear()
-            for ln in (self._lanes or []):
-                ln["mem"].clear()
 
     def _forward_lane(self, ln, x, _pre_relu):
         rt, enc, mem, head = ln["rt"], ln["enc"], ln["mem"], ln["head"]
@@ -150,11 +149,14 @@ class DepthAnythingV2(_EngineOwner):
         e = self._engines()
         rt = e["rt"]
         x = x.to(device=rt.device, dtype=torch.float32).contiguous()
-        B = x.shape[0]
+        B, _, H, W = x.shape
+        e["mem"].prepare(B, (H // 14) * (W // 14))
         nl = int(os.environ.get("VDN_STREAMS", "2"))
         if nl < 2 or B < int(os.environ.get("VDN_LANE_MIN_BATCH", "4")) or B % nl:
             rt.cu_hint = 0
-            return self._forward_lane(dict(rt=rt, enc=e["enc"], mem=e["mem"], head=e["head"]), x, _pre_relu)
+            out = self._forward_lane(dict(rt=rt, enc=e["enc"], mem=e["mem"], head=e["head"]), x, _pre_relu)
+            e["mem"].commit()
+            return out
         lanes = self._stream_lanes(nl)
         for ln in lanes:
             ln["rt"].cu_hint = 256 // nl  # each lane's GEMM tiles are sized for its share of the CUs
@@ -166,6 +168,7 @@ class DepthAnythingV2(_EngineOwner):
                 outs.append(self._forward_lane(ln, xs.contiguous(), _pre_relu))
         for ln in lanes:
             cur.wait_stream(ln["stream"])
+        e["mem"].commit()
         return torch.cat(outs, dim=0)
 
     @torch.no_grad()

@@ -2,23 +2,26 @@
 backend "nccl" (= RCCL over xGMI); every function also runs on CPU tensors under "gloo", which is how
 tests/test_dist.py covers it without GPUs.
 
-Two levels, both new design (the reference has no multi-GPU inference):
+Both levels are new design (the reference has no multi-GPU inference):
 
-* windows — `window_owner`, `infer_video_depth_sharded`: the 32-frame windows of a clip are
-  independent given the input frames (vdn.util.window_table), so they are dealt round-robin to the
-  ranks; the only communication is one all-gather of the per-window depth maps for the (cheap,
-  sequential) host stitcher. No data-path collective.
+* windows — `plan_schedule`, `infer_video_depth_sharded`: the 32-frame windows of a clip are independent
+  given the input frames (vdn.util.window_table). Full rounds deal one window to every rank; the windows
+  left over for the last, partial round are each FRAME-SHARDED over a group of ranks, so no rank idles:
+  12 windows on 8 GPUs = 8 whole windows + 4 windows on 2 GPUs each = 1.5 window-times instead of 2
+  (ideal strong-scaling efficiency 1.0 instead of 0.75). The per-window depth maps are gathered to rank 0
+  once per clip for the (cheap, sequential) stitcher.
 
-* frames inside a window — `FrameShardExchange`: the encoder and every convolution are per-frame,
-  only the 4 temporal modules mix frames, and they do so independently per pixel. Each rank keeps
+* frames inside a window — `FrameShardExchange`, `shard_core`: the encoder and every convolution are
+  per-frame, only the 4 temporal modules mix frames, and they do so independently per pixel. Each rank keeps
   T/P frames; around each temporal module the activations are re-sharded frames<->pixels with an
-  all-to-all (each rank then holds all T frames of 1/P of the pixels), which moves 1/P of what an
-  all-gather of the module input would and lets the module's GEMMs scale with P as well.
-  xGMI is point-to-point (7 links per GPU), and an all-to-all uses all of them at once.
+  all-to-all (each rank then holds all T frames of 1/P of the pixels). An all-gather of the module input
+  (the north star's first suggestion) would move P times the bytes and make every rank project K/V for all
+  T frames; the all-to-all moves 1/P of that and lets the module's GEMMs scale with P as well. xGMI is
+  point-to-point (7 links per GPU), and an all-to-all uses all of them at once.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -35,34 +38,65 @@ def rank(group=None) -> int:
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
-# --------------------------------------------------------------------------------------------- windows
+# --------------------------------------------------------------------------------------------- schedule
 def window_owner(n_windows: int, nranks: int) -> List[int]:
-    """Round-robin: window w runs on rank w % nranks (12 windows of a 256-frame clip on 8 GPUs: 2 rounds)."""
+    """Plain round-robin (window w on rank w % nranks); kept for callers that want whole windows only."""
     return [w % nranks for w in range(n_windows)]
 
 
-def gather_windows(local: torch.Tensor, n_windows: int, group=None) -> Optional[torch.Tensor]:
-    """local: this rank's windows stacked in ascending window order [n_local, 32, h, w] (may be empty).
-    Returns [n_windows, 32, h, w] in window order on every rank (all-gather of equal-sized slabs)."""
-    P, r = world(group), rank(group)
-    if P == 1:
-        return local
-    per = (n_windows + P - 1) // P
-    slab = local.new_zeros((per,) + tuple(local.shape[1:]))
-    slab[: local.shape[0]] = local
-    parts = [torch.empty_like(slab) for _ in range(P)]
-    dist.all_gather(parts, slab, group=group)
-    out = []
-    for w in range(n_windows):
-        out.append(parts[w % P][w // P])
-    return torch.stack(out)
+def plan_schedule(n_windows: int, nranks: int, frames_per_window: int = util.INFER_LEN) -> List[Tuple[int, int, int]]:
+    """Jobs (window, first_rank, group_size) in execution order. Whole windows (group_size 1) fill the full
+    rounds; the `n_windows % nranks` windows of the last round are each sharded by frame over a group of
+    `group_size` consecutive ranks (a power of two that divides the frames of a window)."""
+    jobs = []
+    full = (n_windows // nranks) * nranks
+    for w in range(full):
+        jobs.append((w, w % nranks, 1))
+    rem = n_windows - full
+    if rem:
+        g = 1
+        while g * 2 * rem <= nranks and frames_per_window % (g * 2) == 0:
+            g *= 2
+        for j in range(rem):
+            jobs.append((full + j, j * g, g))
+    return jobs
 
 
+def schedule_rounds(n_windows: int, nranks: int) -> float:
+    """Window-times the slowest rank spends (ideal, no exchange cost): DESIGN.md's expected efficiency is
+    n_windows / (nranks * schedule_rounds)."""
+    load = [0.0] * nranks
+    for _, r0, g in plan_schedule(n_windows, nranks):
+        for r in range(r0, r0 + g):
+            load[r] += 1.0 / g
+    return max(load)
+
+
+_GROUPS: Dict[Tuple[int, int], object] = {}
+
+
+def _subgroups(nranks: int, g: int):
+    """Process groups of `g` consecutive ranks (aligned blocks). Collective: every rank creates every group,
+    in the same order (torch.distributed.new_group contract)."""
+    if g == 1 or nranks == 1:
+        return None
+    key = (nranks, g)
+    if key not in _GROUPS:
+        _GROUPS[key] = [dist.new_group(list(range(b, b + g))) for b in range(0, nranks - g + 1, g)]
+    return _GROUPS[key]
+
+
+# --------------------------------------------------------------------------------------------- driver
 def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size: int = 518, group=None,
-                              forward=None):
-    """Window-parallel twin of VideoDepthAnything.infer_video_depth: identical output on every rank.
-    `forward(window_input [1,32,3,H,W]) -> [1,32,H,W]` defaults to model.forward (tests inject a stub)."""
-    P, r = world(group), rank(group)
+                              forward: Optional[Callable] = None, forward_sharded: Optional[Callable] = None,
+                              all_ranks: bool = True):
+    """Multi-GPU twin of VideoDepthAnything.infer_video_depth (video_depth.py:67-156) over the default process
+    group. Returns (f32 [N,h,w], target_fps) on rank 0 — and on every rank when `all_ranks` (one broadcast of
+    the stitched clip) — else (None, target_fps).
+    `forward(window [1,32,3,H,W]) -> [1,32,H,W]` and `forward_sharded(local frames [1,32/g,3,H,W], group) ->
+    [1,32/g,H,W]` default to the model's methods (tests inject stubs)."""
+    assert group is None, "the schedule builds its own subgroups of the default group"
+    P, r = world(), rank()
     fh, fw = frames[0].shape[:2]
     ratio = max(fh, fw) / min(fh, fw)
     if ratio > 1.78:
@@ -70,38 +104,84 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
         input_size = round(input_size / 14) * 14
     n = frames.shape[0]
     table = util.window_table(n)
-    owner = window_owner(len(table), P)
+    T = util.INFER_LEN
+    jobs = plan_schedule(len(table), P, T)
     fwd = forward if forward is not None else model.forward
-    prep = model.preprocess_frames if hasattr(model, "preprocess_frames") else None
-    mine = []
-    for w, idxs in enumerate(table):
-        if owner[w] != r:
-            continue
+    fwd_sh = forward_sharded if forward_sharded is not None else getattr(model, "forward_sharded", None)
+    prep = getattr(model, "preprocess_frames", None)
+    resize = getattr(model, "resize_depth", None)
+    if hasattr(model, "_engines"):
+        dev = model._engines()["rt"].device
+    else:
+        dev = torch.device("cpu")
+    groups = {g: _subgroups(P, g) for g in sorted({j[2] for j in jobs})}  # collective: before any rank-local branch
+
+    def net_input(idxs: Sequence[int]) -> torch.Tensor:
         need = sorted(set(idxs))
         pos = {f: i for i, f in enumerate(need)}
         net = prep(frames[need], input_size) if prep else torch.from_numpy(frames[need]).float()
-        cur = net[[pos[f] for f in idxs]][None]
-        d = fwd(cur)[0]
-        mine.append(model.resize_depth(d, fh, fw) if hasattr(model, "resize_depth") else d)
-    dev = mine[0].device if mine else (net.device if prep else torch.device("cpu"))
-    local = torch.stack(mine) if mine else torch.zeros((0, util.INFER_LEN, fh, fw), device=dev)
-    allw = gather_windows(local.float().contiguous(), len(table), group)
-    if allw.is_cuda and hasattr(model, "_engines"):  # stitch on the device, one D2H per clip
-        from .video_depth import DeviceStitcher
-        st = DeviceStitcher(model._engines()["rt"], len(table), fh, fw)
-        for w in range(len(table)):
-            st.push(allw[w])
-        return st.result(n).cpu().numpy(), target_fps
-    dn = allw.cpu().numpy()
-    depth_list = [dn[w, i] for w in range(len(table)) for i in range(util.INFER_LEN)]
-    return util.stitch(depth_list, n), target_fps
+        return net[[pos[f] for f in idxs]][None]
+
+    pieces: List[torch.Tensor] = []   # this rank's depth frames in job order
+    for (w, r0, g) in jobs:
+        if not (r0 <= r < r0 + g):
+            continue
+        if g == 1:
+            d = fwd(net_input(table[w]))[0]
+        else:
+            Tl = T // g
+            k = r - r0
+            d = fwd_sh(net_input(table[w][k * Tl:(k + 1) * Tl]), groups[g][r0 // g])[0]
+        pieces.append((resize(d, fh, fw) if resize else d).float())
+
+    # ---- gather every rank's frames to rank 0 (equal slabs; the schedule tells who holds what)
+    counts = [0] * P
+    for (_, r0, g) in jobs:
+        for q in range(r0, r0 + g):
+            counts[q] += T // g
+    slab = torch.zeros((max(counts), fh, fw), dtype=torch.float32, device=dev)
+    if pieces:
+        cat = torch.cat(pieces)
+        slab[: cat.shape[0]].copy_(cat)
+    if P > 1:
+        parts = [torch.empty_like(slab) for _ in range(P)] if r == 0 else None
+        dist.gather(slab, parts, dst=0)
+    else:
+        parts = [slab]
+    out = None
+    if r == 0:
+        allw = torch.empty((len(table), T, fh, fw), dtype=torch.float32, device=dev)
+        cursor = [0] * P
+        for (w, r0, g) in jobs:
+            Tl = T // g
+            for k in range(g):
+                q = r0 + k
+                allw[w, k * Tl:(k + 1) * Tl].copy_(parts[q][cursor[q]:cursor[q] + Tl])
+                cursor[q] += Tl
+        if allw.is_cuda and hasattr(model, "_engines"):  # stitch on the device, one D2H per clip
+            from .video_depth import DeviceStitcher
+            st = DeviceStitcher(model._engines()["rt"], len(table), fh, fw)
+            for w in range(len(table)):
+                st.push(allw[w])
+            out = st.result(n)
+        else:
+            dn = allw.cpu().numpy()
+            out = torch.from_numpy(util.stitch([dn[w, i] for w in range(len(table)) for i in range(T)], n)).to(dev)
+    if all_ranks and P > 1:
+        if r != 0:
+            out = torch.empty((n, fh, fw), dtype=torch.float32, device=dev)
+        out = out.contiguous()
+        dist.broadcast(out, src=0)
+    return (None if out is None else out.cpu().numpy()), target_fps
 
 
 # --------------------------------------------------------------------------------------------- frames
 class FrameShardExchange:
     """Re-shard [frames, pixels, channels] activations between 'my frames, all pixels' and
     'all frames, my pixels' with one all-to-all each way. Pixels are padded to a multiple of the
-    world size (37*37 = 1369 is not divisible by 8); pad rows are zeros and are dropped on the way back."""
+    world size (37*37 = 1369 is not divisible by 8); pad rows are zeros and are dropped on the way back.
+    Each direction costs ONE staging copy (the pad + rank-major permute of the send buffer, or its inverse on
+    the receive side); the other side of each all-to-all is used in place."""
 
     def __init__(self, T: int, group=None):
         self.group = group
@@ -119,10 +199,12 @@ class FrameShardExchange:
         P, HWp = self.P, self.pix_per_rank(HW)
         if P == 1:
             return x
-        send = x.new_zeros((P, Tl, HWp, c))
-        xp = x.new_zeros((Tl, P * HWp, c))
-        xp[:, :HW] = x
-        send.copy_(xp.reshape(Tl, P, HWp, c).permute(1, 0, 2, 3))
+        send = x.new_zeros((P, Tl, HWp, c)) if P * HWp != HW else x.new_empty((P, Tl, HWp, c))
+        full = HW // HWp                       # shards completely covered by real pixels
+        if full:
+            send[:full].copy_(x[:, :full * HWp].unflatten(1, (full, HWp)).permute(1, 0, 2, 3))
+        if full < P and HW > full * HWp:
+            send[full, :, :HW - full * HWp].copy_(x[:, full * HWp:])
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
         return recv.reshape(P * Tl, HWp, c)  # rank-major == frame order (rank q owns frames q*Tl..)
@@ -133,12 +215,34 @@ class FrameShardExchange:
         if P == 1:
             return y
         T, HWp, c = y.shape
-        send = y.reshape(P, self.Tl, HWp, c).contiguous()
+        send = y.reshape(P, self.Tl, HWp, c)
+        if not send.is_contiguous():
+            send = send.contiguous()
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
         # recv[q] = my frames' pixel shard q
-        return recv.permute(1, 0, 2, 3).reshape(self.Tl, P * HWp, c)[:, :HW].contiguous()
+        out = y.new_empty((self.Tl, HW, c))
+        full = HW // HWp
+        if full:
+            out[:, :full * HWp].unflatten(1, (full, HWp)).copy_(recv[:full].permute(1, 0, 2, 3))
+        if full < P and HW > full * HWp:
+            out[:, full * HWp:].copy_(recv[full, :, :HW - full * HWp])
+        return out
 
     def bytes_per_module(self, HW: int, c: int, planes: int = 2, elem: int = 2) -> int:
         """payload one rank sends per direction for one temporal module"""
         return self.Tl * self.pix_per_rank(HW) * (self.P - 1) * c * planes * elem
+
+
+def shard_core(exch: FrameShardExchange, planes: List[torch.Tensor], HW: int, core: Callable) -> List[torch.Tensor]:
+    """The staging around one temporal module of a frame-sharded window, as a pure function of tensors:
+    every plane [Tl*HW, c] of this rank's frames (hi and lo planes travel as separate all-to-alls, no
+    concatenation) -> all frames of this rank's pixel shard -> `core(list of [T*D, c] planes, D)` (the per-pixel
+    temporal block, any callable) -> back to this rank's frames [Tl*HW, c']. Used by TemporalEngine.run_sharded
+    with the HIP core and by tests/test_dist.py with a CPU stand-in under gloo."""
+    Tl = exch.Tl
+    px = [exch.frames_to_pixels(p.reshape(Tl, HW, p.shape[-1])) for p in planes]
+    D = px[0].shape[1]
+    out = core([p.reshape(exch.T * D, p.shape[-1]) for p in px], D)
+    back = [exch.pixels_to_frames(o.reshape(exch.T, D, o.shape[-1]), HW) for o in out]
+    return [b.reshape(Tl * HW, b.shape[-1]) for b in back]

@@ -211,23 +211,20 @@ class TemporalEngine:
     def run_sharded(self, x, exch, HW: int):
         """Frame-sharded window (vdn/dist.py): x holds this rank's Tl frames. GroupNorm and proj_out run
         on the frame shard; the per-pixel core runs on all T frames of this rank's pixel shard, with one
-        all-to-all before and one after (hi and lo planes travel together)."""
+        all-to-all before and one after per plane (staging: vdn.dist.shard_core, a pure function of tensors
+        that tests/test_dist.py drives under gloo). Buffers are consumed in stream order, so plain local
+        references keep them alive long enough."""
+        from .dist import shard_core
         from .runtime import HL
-        c, Tl = self.c, exch.Tl
+        Tl = exch.Tl
         g = self.gn(x, Tl, HW)
 
-        def planes(t):
-            return torch.cat([t.hi.reshape(Tl, HW, c)] + ([t.lo.reshape(Tl, HW, c)] if t.lo is not None else []), dim=-1)
+        def core(planes, D):
+            hh = self.core(HL(planes[0], planes[1] if len(planes) > 1 else None), 1, exch.T, D)
+            return [hh.hi] + ([hh.lo] if hh.lo is not None else [])
 
-        gp = exch.frames_to_pixels(planes(g))                     # [T, HWp, c * planes]
-        D = gp.shape[1]
-        gsh = HL(gp[..., :c].contiguous().reshape(-1, c), gp[..., c:].contiguous().reshape(-1, c) if g.lo is not None else None)
-        hh = self.core(gsh, 1, exch.T, D)
-        hp = torch.cat([hh.hi.reshape(exch.T, D, c)] + ([hh.lo.reshape(exch.T, D, c)] if hh.lo is not None else []), dim=-1)
-        hl = exch.pixels_to_frames(hp, HW)                        # [Tl, HW, c * planes]
-        hloc = HL(hl[..., :c].contiguous().reshape(-1, c), hl[..., c:].contiguous().reshape(-1, c) if hh.lo is not None else None)
-        self.rt._keep.append((gsh, hloc))
-        return self.out(hloc, x, Tl * HW)
+        back = shard_core(exch, [g.hi] + ([g.lo] if g.lo is not None else []), HW, core)
+        return self.out(HL(back[0], back[1] if len(back) > 1 else None), x, Tl * HW)
 
 
 # =============================================================================================
@@ -401,38 +398,65 @@ class MemoryEngine:
                 nw=pack.f32(b.norm.weight), nb=pack.f32(b.norm.bias),
                 w1=pack.linear(b.pwconv1.weight, h), b1=pack.f32(b.pwconv1.bias),
                 w2=pack.linear(b.pwconv2.weight, h), b2=pack.f32(b.pwconv2.bias), g=pack.f32(b.gamma)))
-        self.count = 0
-        self._shape = None
+        # Bank state shared by every lane copy of this engine (DepthAnythingV2._stream_lanes): ONE ring for the whole
+        # batch, lane i of n works on batch rows [i B/n, (i+1) B/n) of it, so laned and single-lane calls see the
+        # same memory and `count` advances once per forward (commit()).
+        self.state = {"count": 0, "shape": None}
+        self.lane = (0, 1)
+        self.bank_rt = rt
         self._rope = {}
-        self._nomem_ready = None
+        self._nomem = {}
 
     def clear(self):
-        self.count = 0
-        self._shape = None
+        self.state["count"] = 0
+        self.state["shape"] = None
 
     @property
     def S(self):
-        return min(self.count, self.max_len)
+        return min(self.state["count"], self.max_len)
 
     def _rope_for(self, side):
         if side not in self._rope:
             self._rope[side] = pack.rope_table(side, side, 64, device=self.rt.device)
         return self._rope[side]
 
-    def _bank(self, B, P):
-        rt, Hh = self.rt, self.heads
+    def prepare(self, B: int, P: int):
+        """Called once per forward on the caller's stream BEFORE any lane forks: checks the bank against the batch
+        (the reference asserts on a batch mismatch between the frame and its memories, memory_attention.py:135-137)
+        and makes sure the ring and the RoPE table exist."""
+        st = self.state
+        if st["shape"] != (B, P):
+            if st["count"] > 0:
+                raise RuntimeError(f"memory bank holds {self.S} frame(s) of batch/grid {st['shape']} but the new frame is "
+                                   f"{(B, P)}: call clear_memory() before changing the batch size or resolution")
+            st["shape"] = (B, P)
+        side = int(math.sqrt(P))
+        assert side * side == P, "MemoryBlock assumes square inputs (memory_block.py:85)"
+        self._rope_for(side)
+        self._bank_full(B, P)
+
+    def commit(self):
+        self.state["count"] += 1
+
+    def _bank_full(self, B, P):
+        rt, Hh = self.bank_rt, self.heads
         tp = ceil_to(self.max_len * P, 64)
         ks = [rt.hbuf(f"mem_k{l}", (B * Hh, tp, 64), zero=True) for l in range(len(self.layers))]
         vs = [rt.hbuf(f"mem_vt{l}", (B * Hh, 64, tp), zero=True) for l in range(len(self.layers))]
         return ks, vs, tp
 
+    def _bank(self, B, P):
+        """This lane's rows of the ring: B is the lane's batch."""
+        i, n = self.lane
+        ks, vs, tp = self._bank_full(B * n, P)
+        r0, nr = i * B * self.heads, B * self.heads
+        return [k.narrow0(r0, nr) for k in ks], [v.narrow0(r0, nr) for v in vs], tp
+
     def forward(self, feat_f32: torch.Tensor, B: int, P: int) -> torch.Tensor:
         """feat_f32 [B*P, C] (final-normed tap 4) -> half [B*P, C] (memory_block.py:92-125)."""
         rt, C, Hh = self.rt, self.C, self.heads
-        if self._shape != (B, P):
-            self._shape, self.count = (B, P), 0
+        assert self.state["shape"] == (B * self.lane[1], P), "MemoryEngine.prepare() not called for this batch"
         side = int(math.sqrt(P))
-        assert side * side == P, "MemoryBlock assumes square inputs (memory_block.py:85)"
         M = B * P
         cs = self._rope_for(side)
         pp = ceil_to(P, 64)
@@ -449,8 +473,9 @@ class MemoryEngine:
         if S == 0:
             # empty bank: keys/values come from no_mem_embed broadcast to P tokens (memory_block.py:115-123)
             nk, nk_pad = P, pp
-            a_nm = rt.to_half(self.no_mem.expand(M, C).contiguous())
-            rt._keep.append(a_nm)
+            if M not in self._nomem:  # built once per (lane, batch): the broadcast no_mem_embed rows as half planes
+                self._nomem[M] = rt.to_half(self.no_mem.expand(M, C).contiguous())
+            a_nm = self._nomem[M]
             ks = [rt.hbuf(f"nomem_k{l}", (B * Hh, pp, 64), zero=True) for l in range(len(self.layers))]
             vs = [rt.hbuf(f"nomem_vt{l}", (B * Hh, 64, pp), zero=True) for l in range(len(self.layers))]
             for l, L in enumerate(self.layers):
@@ -502,11 +527,10 @@ class MemoryEngine:
             rt.gemm(n, cx["w1"], M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4)
             rt.gemm(h4, cx["w2"], M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=(x if j == 0 else feat))
         ks, vs, tp = self._bank(B, P)
-        slot = self.count % self.max_len
+        slot = self.state["count"] % self.max_len  # commit() advances the count once every lane has pushed
         cs = self._rope_for(int(math.sqrt(P)))
         for l, L in enumerate(self.layers):
             rt.gemm(feat, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
                     heads=dict(dst=[ks[l], vs[l]], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
                                tokens=P, tok_off=slot * P, tpad=tp))
-        self.count += 1
         return feat

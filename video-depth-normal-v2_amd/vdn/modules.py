@@ -2,7 +2,7 @@
 
 These nn.Modules only HOLD weights (so `load_state_dict(torch.load(ckpt))`, `.to(device)`,
 `.state_dict()` behave as for the reference); they never run torch compute. The forward pass lives
-in vdn/engine.py and runs on libvdn_hip.so. tests/test_schema.py checks the key/shape schema
+in vdn/engine.py and runs on libvdn_hip.so. tests/test_host.py checks the key/shape schema
 against the one dumped from the imported reference (tests/golden/schema_*.json).
 """
 from __future__ import annotations

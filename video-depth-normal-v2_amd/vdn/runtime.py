@@ -1,19 +1,15 @@
-"""Device runtime: workspace arena, launch recording, and tensor-level wrappers over the C-ABI.
+"""Device runtime: workspace arena and tensor-level wrappers over the C-ABI.
 
 PyTorch is plumbing here (device memory, streams); every arithmetic op on the path is a launch of
 libvdn_hip.so. Launches go to torch's current stream, so the caller's stream semantics (and
-torch.cuda.CUDAGraph capture) apply unchanged.
-
-Recording: with `rt.record(key)` every launch is also appended to a plan; `rt.replay(key)` re-issues
-the same ctypes calls without re-deriving shapes or descriptors (workspace pointers are stable
-because buffers come from the arena by name).
+torch.cuda.CUDAGraph capture) apply unchanged. Workspace pointers are stable: buffers come from the
+arena by (name, shape, dtype) and nothing is allocated per call after warm-up.
 """
 from __future__ import annotations
 
 import os
 
 import ctypes as C
-from contextlib import contextmanager
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -56,6 +52,10 @@ class HL:
     def data_ptr(self):
         return self.hi.data_ptr()
 
+    def narrow0(self, start: int, length: int) -> "HL":
+        """Rows [start, start+length) of the leading dimension, both planes (a contiguous view)."""
+        return HL(self.hi.narrow(0, start, length), None if self.lo is None else self.lo.narrow(0, start, length))
+
     def zero_(self):
         self.hi.zero_()
         if self.lo is not None:
@@ -82,11 +82,8 @@ class Runtime:
         self.dt = _TDT[half]
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)
         self._bufs: Dict[tuple, torch.Tensor] = {}
-        self._plans: Dict[object, list] = {}
-        self._rec: Optional[list] = None
-        self._keep: List[object] = []
         self.cu_hint = 0  # vdn_gemm_desc.cu_hint: 0 = whole chip; lanes that co-run set their share
-        self.timing: Optional[list] = None  # bench.py: [(tag, start_event, end_event)] for tagged launches
+        self.timing: Optional[list] = None  # bench.py: [(tag, start_event, end_event, flop)] for tagged launches
 
     # ------------------------------------------------------------------ memory
     def buf(self, name: str, shape: Sequence[int], dtype: torch.dtype, zero: bool = False) -> torch.Tensor:
@@ -112,42 +109,18 @@ class Runtime:
     def workspace_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
-    # ------------------------------------------------------------------ launch / record / replay
-    def _launch(self, fn, *args, tag: Optional[str] = None):
+    # ------------------------------------------------------------------ launch
+    def _launch(self, fn, *args, tag: Optional[str] = None, flop: float = 0.0):
         if tag is not None and self.timing is not None:
             # HIP events on the launch stream (torch's current stream is the stream the kernel runs on)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
             e.record()
-            self.timing.append((tag, s, e))
+            self.timing.append((tag, s, e, flop))
         else:
             rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
         abi.check(rc, fn.__name__)
-        if self._rec is not None:
-            self._rec.append((fn, args))
-
-    @contextmanager
-    def record(self, key):
-        self._rec = []
-        try:
-            yield
-            self._plans[key] = self._rec
-        finally:
-            self._rec = None
-
-    def has_plan(self, key) -> bool:
-        return key in self._plans
-
-    def replay(self, key):
-        s = torch.cuda.current_stream(self.device).cuda_stream
-        for fn, args in self._plans[key]:
-            rc = fn(*args, s)
-            if rc != 0:
-                abi.check(rc, fn.__name__)
-
-    def drop_plans(self):
-        self._plans.clear()
 
     # ------------------------------------------------------------------ ops
     @staticmethod
@@ -217,14 +190,8 @@ class Runtime:
         if self.split:  # split-K scratch for launches whose tile grid covers a fraction of the chip (include/vdn.h)
             ws = self.buf("splitk_ws", (32 * 1024 * 1024,), torch.float32)
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
-        self._launch(abi.lib.vdn_gemm, C.byref(d), tag=tag)
-        self._keep_alive(d)
+        self._launch(abi.lib.vdn_gemm, C.byref(d), tag=tag, flop=2.0 * M * N * K)  # the library copies the descriptor before it returns
         return out
-
-    def _keep_alive(self, obj):
-        # descriptors referenced by recorded plans must outlive them
-        if self._rec is not None:
-            self._keep.append(obj)
 
     def layernorm(self, x: torch.Tensor, rows: int, Cn: int, w, b, eps: float, *, out_h=None, out_f=None, addvec=None,
                   alpha: float = 1.0, addtab=None, tab_div: int = 1, tab_mod: int = 1, out_group: int = 0):
@@ -237,7 +204,7 @@ class Runtime:
                    tag: Optional[str] = None):
         (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
         self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
-                     vl, ol, B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag)
+                     vl, ol, B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag, flop=4.0 * B * H * nq * nk * 64)
 
     def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
         (qkv, ql), (out, ol) = _hl(qkv), _hl(out)
