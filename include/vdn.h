@@ -171,6 +171,12 @@ int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, cons
 int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                    const void* K_lo, const void* Vt_lo, void* out_lo, int B, int H, int nq, int nq_pad, int nk,
                    int nk_pad, float scale, vdn_stream stream);
+/* Split-plane mode only: MFMA products per P V term. 2 (default): the softmax weights, born in registers, are
+ * rounded once to 16 bits and the row sum uses the same rounded weights (O = sum p~ V / sum p~, V at 21 bits): each
+ * weight is off by <= 2^-11 relative, common factors cancel. 3: P is split into hi / lo planes too (every output
+ * within ~1e-6 of fp64 at ~13 % more kernel time). Process-wide; set before launching. VDN_ATTN_PV3=1 = default 3. */
+int vdn_flash_attn_set_pv_products(int n);
+int vdn_flash_attn_get_pv_products(void);
 
 /* Temporal attention over <=64 frames per (pixel, head) (32 in the 32-frame windows, 64 in the v5 refiner): qkv half [(b f), D, 3c] packed
  * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)
@@ -272,6 +278,43 @@ int vdn_refine_scale(const float* x, const float* median, int frames, size_t n, 
 int vdn_refine_pack(const float* d, float* out, int frames, int H, int W, int normals, vdn_stream stream);
 int vdn_refine_finish(const float* scaled, const float* depth, float w, float b, float max_depth, int residual, float* out,
                       size_t n, vdn_stream stream);
+
+/* Fused depth tail (depth_anything_v2/dpt.py:146-151; video_depth_anything/dpt_temporal.py:106-111 runs the same ops
+ * in micro-batches): bilinear resize (align_corners=True) of the split-plane NHWC map x [B, IH, IW, C] to (OH, OW),
+ * Conv3x3(C -> 32, pad 1) + bias2 + ReLU, Conv1x1(32 -> 1) + b1 [+ ReLU when relu != 0] -> depth f32 [B, OH, OW].
+ * The up-sampled map and the 32-channel map stay on chip. w / w_lo: split planes [32, ldb] with K = tap * C + ci
+ * (tap = 3 ky + kx; vdn.pack.conv3x3_taps), ldb >= 9 C; C a multiple of 32; 3 MFMA products per term.          */
+int vdn_depth_tail(int dt, const void* x, const void* x_lo, int B, int IH, int IW, int C, const void* w, const void* w_lo,
+                   int ldb, const float* bias2, const float* w1, float b1, float* depth, int OH, int OW, int relu,
+                   vdn_stream stream);
+
+/* One-time weight packing ON THE DEVICE, so that a host in any language can feed the library from the reference's
+ * fp32 parameter tensors as torch.nn stores them (vdn/pack.py is a thin caller of these). `w` is the contiguous fp32
+ * parameter, (hi, lo) the [rows, ldb] planes vdn_gemm reads (lo may be NULL for the 1-product modes): K contiguous,
+ * zero padded to ldb = vdn_pack_ldb(..) (a multiple of 64); hi = nearest(w), lo = nearest(w - hi).
+ *   kind                 parameter (d0, d1, d2)                rows              K order
+ *   VDN_PACK_LINEAR      [N, K] (d0 = N, d1 = K); also 1x1 convs and the 14x14 patch embedding (K = 588)
+ *   VDN_PACK_CONV3X3     [Co, Ci, 3, 3] (d0 = Co, d1 = Ci)      Co                (ci/64, tap, ci%64) if Ci % 64 == 0 else (tap, ci)
+ *   VDN_PACK_CONV3X3_TAPS  same                                 Co                (tap, ci)            [vdn_depth_tail]
+ *   VDN_PACK_CONVT       [Ci, Co, k, k], kernel == stride (d0 = Ci, d1 = Co, d2 = k)   k*k*Co rows (ky, kx, co); K = ci
+ *   VDN_PACK_GEGLU       [2 Nh, K] = [h ; gate]                 2 Nh, 16-row blocks alternating h / gate   [VDN_ST_GEGLU]
+ *   VDN_PACK_ROPE        [N, K], N % 64 == 0                    per head (2i, 2i+1) -> [re 0-15 | im 0-15 | re 16-31 | im 16-31]
+ * Concatenated projections (q|k|v) are packed one after the other into row ranges of one plane (hi + row0 * ldb).
+ * vdn_pack_bias writes the matching bias order (row permutation / ConvTranspose repeat) as fp32 [rows].
+ * Reference layouts: nn.Linear / nn.Conv2d / nn.ConvTranspose2d weights of dinov2_layers/*.py, util/blocks.py,
+ * dpt.py:55-83, motion_module/attention.py:370-384 (GEGLU), sam2/modeling/sam/transformer.py:279-281 (RoPE q/k).   */
+enum { VDN_PACK_LINEAR = 0, VDN_PACK_CONV3X3 = 1, VDN_PACK_CONV3X3_TAPS = 2, VDN_PACK_CONVT = 3, VDN_PACK_GEGLU = 4,
+       VDN_PACK_ROPE = 5 };
+int vdn_pack_rows(int kind, int d0, int d1, int d2);  /* rows of the packed planes, or a negative vdn_status */
+int vdn_pack_ldb(int kind, int d0, int d1, int d2);   /* plane stride in elements */
+int vdn_pack_weight(int dt, int kind, const float* w, int d0, int d1, int d2, void* hi, void* lo, int ldb, vdn_stream stream);
+int vdn_pack_bias(int kind, const float* b, int d0, int d1, int d2, float* out, vdn_stream stream);
+
+/* Workspace sizing (the library allocates nothing): bytes of split-K scratch worth passing as vdn_gemm_desc.splitk_ws
+ * for this descriptor (0 = the shape never splits), and the partial-sum buffer of vdn_groupnorm.
+ * See also vdn_stitch_workspace_bytes / vdn_frame_median_workspace_bytes.                                       */
+size_t vdn_gemm_workspace_bytes(const vdn_gemm_desc* d);
+size_t vdn_groupnorm_workspace_bytes(int frames, int groups, int nsplit);
 
 /* misc */
 int vdn_cast(const void* x, int x_dt, void* y, int y_dt, size_t n, vdn_stream stream);

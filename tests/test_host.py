@@ -122,17 +122,15 @@ def test_product_refuses_cpu():
         m.forward(torch.zeros(1, 3, 28, 28))
 
 
-def test_packing_permutations():
-    from vdn import pack
-    p = pack.rope_perm(128, "cpu")
-    assert sorted(p.tolist()) == list(range(128))
-    # head 0: packed tile 0 = even columns of pairs 0..15, tile 1 = their odd partners
-    assert p[:16].tolist() == [2 * i for i in range(16)] and p[16:32].tolist() == [2 * i + 1 for i in range(16)]
-    assert p[32:48].tolist() == [32 + 2 * i for i in range(16)]
-    w = torch.arange(64 * 4, dtype=torch.float32).reshape(64, 4)
-    b = torch.arange(64, dtype=torch.float32)
-    wp, bp = pack.geglu(w, b, torch.float16)
-    assert bp[:16].tolist() == list(range(16)) and bp[16:32].tolist() == list(range(32, 48))
-    assert wp.shape == (64, 64)
+def test_rope_table_and_pack_geometry():
+    """Host-visible pieces of the packing ABI (the packers themselves run on the device: tests/test_gpu_ops.py)."""
+    from vdn import _abi, pack
     cs = pack.rope_table(3, 3, 64)
     assert cs.shape == (9, 32, 2) and torch.allclose(cs[0, :, 0], torch.ones(32))
+    L = _abi.lib
+    assert L.vdn_pack_ldb(_abi.PACK_LINEAR, 1024, 588, 0) == 640 and L.vdn_pack_rows(_abi.PACK_LINEAR, 1024, 588, 0) == 1024
+    assert L.vdn_pack_ldb(_abi.PACK_CONV3X3, 256, 64, 0) == 576 and L.vdn_pack_ldb(_abi.PACK_CONV3X3_TAPS, 32, 32, 0) == 320
+    assert L.vdn_pack_rows(_abi.PACK_CONVT, 256, 256, 4) == 4096 and L.vdn_pack_ldb(_abi.PACK_CONVT, 256, 256, 4) == 256
+    assert L.vdn_pack_rows(_abi.PACK_GEGLU, 48, 64, 0) < 0 and L.vdn_pack_rows(_abi.PACK_ROPE, 100, 64, 0) < 0  # bad row counts
+    assert L.vdn_pack_weight(_abi.F16, 99, None, 1, 1, 0, None, None, 64, None) == -1
+    assert L.vdn_gemm_workspace_bytes(None) == 0 and L.vdn_groupnorm_workspace_bytes(4, 32, 16) == 4 * 16 * 32 * 2 * 4

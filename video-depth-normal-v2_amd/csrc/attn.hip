@@ -12,6 +12,11 @@
 //   ds_read_b128 fragment reads bank-conflict free.
 //   SPLIT: every operand comes as (hi, lo) 16-bit planes and each product is accumulated as
 //   hi*hi + hi*lo + lo*hi (fp32-faithful "x3" mode, see include/vdn.h).
+//   PV2 (SPLIT only, the default): P, which is born in registers, is rounded ONCE to 16 bits (p~) and O accumulates
+//   p~ (V_hi + V_lo): 2 products instead of 3 and no lo split of P on the VALU. The row sum l is accumulated from the
+//   SAME rounded p~ (one v_dot2 per pair), so O / l is an exact convex combination of the (21-bit) V rows with
+//   weights p~ / sum p~: the rounding perturbs each weight by <= 2^-11 relative and any part of it common to a
+//   row cancels in the normalisation (DESIGN.md §3 has the measured end-to-end effect).
 //
 // temporal_attn_kernel — <= 32 frames per (pixel, head): one wave per sequence, fragments loaded
 //   straight from global memory (no LDS), same accumulator-as-operand chaining.
@@ -51,7 +56,7 @@ __device__ __forceinline__ void for_each_slot(F& f) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int DT, bool SPLIT>
+template <int DT, bool SPLIT, bool PV2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_kernel(const typename Half<DT>::T* __restrict__ Q,
                                                          const typename Half<DT>::T* __restrict__ K,
                                                          const typename Half<DT>::T* __restrict__ Vt,
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         o[db] = HT::mfma32(a, pf[c >> 1][c & 1], o[db]);
         if constexpr (SPLIT) {
           const V8 al = *(const V8*)(sV + 2 * TILE + v_addr(db, c));
-          o[db] = HT::mfma32(a, pl[c >> 1][c & 1], o[db]);
+          if constexpr (!PV2) o[db] = HT::mfma32(a, pl[c >> 1][c & 1], o[db]);
           o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
         }
       }
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (HAS_PREV) {
           constexpr int c = j >> 1, db = j & 1;
           if constexpr (q == 0) o[db] = HT::mfma32(a, pf[c >> 1][c & 1], o[db]);
-          if constexpr (q == 1) o[db] = HT::mfma32(a, pl[c >> 1][c & 1], o[db]);
+          if constexpr (q == 1 && !PV2) o[db] = HT::mfma32(a, pl[c >> 1][c & 1], o[db]);  // PV2: a VALU-only slot
           if constexpr (q == 2) o[db] = HT::mfma32(al, pf[c >> 1][c & 1], o[db]);
         }
       } else if constexpr (HAS_NEXT) {
@@ -278,6 +283,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (((k - 6) & 1) == 0) {
           px0 = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2, mb));
           px1 = __builtin_amdgcn_exp2f(fmaf(s[kb][i + 1], scale_log2, mb));
+        } else if constexpr (SPLIT && PV2) {
+          if constexpr (DT == VDN_F16) {  // one packed convert, one dot2 for the row sum of the ROUNDED weights
+            const f16x2 pp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(px0, px1));
+            pf[kb][i >> 3][i & 7] = pp[0]; pf[kb][i >> 3][(i & 7) + 1] = pp[1];
+            ls = __builtin_amdgcn_fdot2(pp, f16x2{(_Float16)1.f, (_Float16)1.f}, ls, false);
+          } else {
+            const T a0 = (T)px0, a1 = (T)px1;
+            pf[kb][i >> 3][i & 7] = a0; pf[kb][i >> 3][(i & 7) + 1] = a1;
+            ls += (float)a0 + (float)a1;
+          }
         } else {
           ls += px0 + px1;
           if constexpr (SPLIT) {
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // P(t) is only consumed by the next iteration's MFMAs: keep LLVM from sinking its computation there.
     asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1]));
-    if constexpr (SPLIT) asm volatile("" : "+v"(pl[0][0]), "+v"(pl[0][1]), "+v"(pl[1][0]), "+v"(pl[1][1]));
+    if constexpr (SPLIT && !PV2) asm volatile("" : "+v"(pl[0][0]), "+v"(pl[0][1]), "+v"(pl[1][0]), "+v"(pl[1][1]));
     if (bump) {  // O is in the old reference (it just received tile t-1): move it to the new one
       asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch: if-converted it costs 16 v_pk_mul per tile
 #pragma unroll
@@ -577,16 +592,26 @@ __global__ __launch_bounds__(256) void temporal_last_kernel(const float* const* 
   for (int e = 0; e < CPL; ++e) store_half(out, out_lo, (size_t)px * c + ch + e, o[e]);
 }
 
+// process-wide: MFMA products per P V term in split mode: 2 (default) or 3. VDN_ATTN_PV3=1 selects 3 at the first use.
+int& pv_products() {
+  static int v = [] { const char* e = getenv("VDN_ATTN_PV3"); return (e && atoi(e) != 0) ? 3 : 2; }();
+  return v;
+}
+
 template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
                  void* outl, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
   using T = typename Half<DT>::T;
   const dim3 grid(((nq + 127) / 128) * B * H);
-  if (Ql)
-    hipLaunchKernelGGL((flash_attn_kernel<DT, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+  const bool pv3 = pv_products() == 3;  // the 3-product P V with P split into hi / lo planes (vdn_flash_attn_set_pv_products)
+  if (Ql && pv3)
+    hipLaunchKernelGGL((flash_attn_kernel<DT, true, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
+  else if (Ql)
+    hipLaunchKernelGGL((flash_attn_kernel<DT, true, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
   else
-    hipLaunchKernelGGL((flash_attn_kernel<DT, false>), grid, dim3(256), 32768, s, (const T*)Q, (const T*)K, (const T*)Vt,
+    hipLaunchKernelGGL((flash_attn_kernel<DT, false, false>), grid, dim3(256), 32768, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)outl, H, nq, nq_pad, nk,
                        nk_pad, sl2);
   VDN_CHECK_LAUNCH();
@@ -612,6 +637,13 @@ int temporal_launch(const void* qkv, void* out, const void* qkv_lo, void* out_lo
 }
 
 }  // namespace
+
+extern "C" int vdn_flash_attn_set_pv_products(int n) {
+  if (n != 2 && n != 3) return VDN_EINVAL;
+  pv_products() = n;
+  return VDN_OK;
+}
+extern "C" int vdn_flash_attn_get_pv_products(void) { return pv_products(); }
 
 extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                               const void* K_lo, const void* Vt_lo, void* out_lo, int B, int H, int nq, int nq_pad, int nk,

@@ -8,8 +8,12 @@ template <> struct Vec4<float> { using V = f32x4; };
 template <> struct Vec4<_Float16> { using V = f16x4; };
 template <> struct Vec4<__bf16> { using V = bf16x4; };
 
-// ---------------------------------------------------------------- LayerNorm: one wave per row
-template <typename XT, int DT>
+// ---------------------------------------------------------------- LayerNorm: one wave per row, persistent
+// A wave walks rows wave_id, wave_id + nwaves, ... and issues the loads of its NEXT row before it reduces the
+// current one, so two rows (8 KiB at C = 1024) per wave are in flight and the grid (<= 8 blocks per CU) has no
+// partial last round: round 1 ran one row per wave with 2740 blocks on 2048 slots (1.34 rounds of pure latency)
+// at 2.7 TB/s. gamma / beta (+ alpha * addvec) are loaded once per wave. NV = 256-channel steps (4 per lane each).
+template <typename XT, int DT, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, int rows, int C,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, const float* __restrict__ addvec, float alpha,
@@ -18,67 +22,85 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
                                                         typename Half<DT>::T* __restrict__ out_l,
                                                         float* __restrict__ out_f) {
   using T = typename Half<DT>::T;
+  using XV = typename Vec4<XT>::V;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  // out_group > 0: drop the first row of every group (the cls token) and compact the rest
-  if (out_group > 0 && row % out_group == 0) return;
-  const size_t orow = out_group > 0 ? (size_t)(row - row / out_group - 1) : (size_t)row;
-  const XT* xr = x + (size_t)row * C;
-  constexpr int NV = 8;  // up to 8 x 256 = 2048 channels, 4 per lane per step
-  float v[NV][4];
-  float sum = 0.f;
+  const int nwaves = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  f32x4 wv[NV], bv[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
     if (c < C) {
-      const typename Vec4<XT>::V xv = *(const typename Vec4<XT>::V*)(xr + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = (float)xv[e];
-      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+      wv[i] = *(const f32x4*)(w + c);
+      bv[i] = *(const f32x4*)(b + c);
+      if (addvec) bv[i] += alpha * *(const f32x4*)(addvec + c);
     }
   }
-  const float mean = wave_sum(sum) / (float)C;
-  float sq = 0.f;
+  auto load = [&](int r, XV (&dst)[NV]) {
+    const XT* xr = x + (size_t)r * C;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = i * 256 + lane * 4;
-    if (c < C) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = v[i][e] - mean;
-        sq += d * d;
-      }
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (c < C) dst[i] = *(const XV*)(xr + c);
     }
-  }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-  const float* tab = addtab ? addtab + (size_t)((row / tab_div) % tab_mod) * C : nullptr;
+  };
+  XV cur[NV], nxt[NV];
+  if (row < rows) load(row, cur);
+  for (; row < rows; row += nwaves) {
+    const int nrow = row + nwaves;
+    if (nrow < rows) load(nrow, nxt);
+    // out_group > 0: drop the first row of every group (the cls token) and compact the rest
+    if (!(out_group > 0 && row % out_group == 0)) {
+      const size_t orow = out_group > 0 ? (size_t)(row - row / out_group - 1) : (size_t)row;
+      f32x4 v[NV];
+      float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = i * 256 + lane * 4;
-    if (c < C) {
-      float y[4];
+      for (int i = 0; i < NV; ++i) {
+        if (i * 256 + lane * 4 < C) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        y[e] = (v[i][e] - mean) * rstd * w[c + e] + b[c + e];
-        if (addvec) y[e] += alpha * addvec[c + e];
-        if (tab) y[e] += tab[c + e];
-      }
-      if (out_f) *(f32x4*)(out_f + orow * C + c) = f32x4{y[0], y[1], y[2], y[3]};
-      if (out_h) {
-        typename Half<DT>::V4 hv, lv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (out_l) { T a, b2; split_rtz(y[e], a, b2); hv[e] = a; lv[e] = b2; }
-          else hv[e] = (T)y[e];
+          for (int e = 0; e < 4; ++e) v[i][e] = (float)cur[i][e];
+          sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
-        *(typename Half<DT>::V4*)(out_h + orow * C + c) = hv;
-        if (out_l) *(typename Half<DT>::V4*)(out_l + orow * C + c) = lv;
+      }
+      const float mean = wave_sum(sum) / (float)C;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        if (i * 256 + lane * 4 < C) {
+          v[i] -= mean;
+          sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+      const float* tab = addtab ? addtab + (size_t)((row / tab_div) % tab_mod) * C : nullptr;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < C) {
+          f32x4 y = v[i] * rstd * wv[i] + bv[i];
+          if (tab) y += *(const f32x4*)(tab + c);
+          if (out_f) *(f32x4*)(out_f + orow * C + c) = y;
+          if (out_h) {
+            typename Half<DT>::V4 hv, lv;
+            if (out_l) {
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                T h0, h1, l0, l1;
+                split2_rtz(y[e], y[e + 1], h0, h1, l0, l1);
+                hv[e] = h0; hv[e + 1] = h1; lv[e] = l0; lv[e + 1] = l1;
+              }
+              *(typename Half<DT>::V4*)(out_l + orow * C + c) = lv;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[e] = (T)y[e];
+            }
+            *(typename Half<DT>::V4*)(out_h + orow * C + c) = hv;
+          }
+        }
       }
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -225,19 +247,40 @@ __global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restric
     store_from_float(y, ydt, i, load_as_float(x, xdt, i));
 }
 
+template <typename XT, int NV>
+int ln_launch_nv(const void* x, int rows, int C, const float* w, const float* b, float eps, const float* addvec,
+                 float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, void* out_l,
+                 int h_dt, float* out_f, hipStream_t s) {
+  // grid = what is resident at once (CUs x blocks the register budget admits), persistent beyond that
+  static const int resident = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layernorm_kernel<XT, VDN_F16, NV>, 256, 0) != hipSuccess || per_cu <= 0)
+      per_cu = 4;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * per_cu;
+    return prop.multiProcessorCount * per_cu;
+  }();
+  const int blocks = (rows + 3) / 4;
+  const dim3 grid(blocks < resident ? blocks : resident);
+  if (h_dt == VDN_BF16)
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16, NV>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, (__bf16*)out_l, out_f);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16, NV>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
 template <typename XT>
 int ln_launch(const void* x, int rows, int C, const float* w, const float* b, float eps, const float* addvec,
               float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, void* out_l,
               int h_dt, float* out_f, hipStream_t s) {
-  const dim3 grid((rows + 3) / 4);
-  if (h_dt == VDN_BF16)
-    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
-                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, (__bf16*)out_l, out_f);
-  else
-    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
-                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f);
-  VDN_CHECK_LAUNCH();
-  return VDN_OK;
+  if (C <= 512)
+    return ln_launch_nv<XT, 2>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, s);
+  if (C <= 1024)
+    return ln_launch_nv<XT, 4>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, s);
+  return ln_launch_nv<XT, 8>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, s);
 }
 
 }  // namespace

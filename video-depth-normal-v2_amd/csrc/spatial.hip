@@ -279,31 +279,60 @@ __global__ __launch_bounds__(128) void mask_down2_kernel(const float* __restrict
   out[i] = o;
 }
 
+// Depthwise 7x7 (pad 3) on f32 NHWC (sam2/modeling/memory_encoder.py:99-117 CXBlock.dwconv). One workgroup owns
+// 8 output rows x all columns x 32 channels: the 14 input rows it needs and the 49 x 32 weights are staged in LDS once
+// (round 1 read every input 49 times through L2: 1.3 GB for a 45 MB tensor), then a thread produces runs of 4 adjacent
+// outputs for 4 channels, re-using each staged input row segment (10 values) for 28 multiply-adds.
+constexpr int DW_TH = 8, DW_CB = 32, DW_PS = 36;  // rows per tile, channels per block, padded pixel stride (floats)
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
                                                       int W, int C, const float* __restrict__ w,
                                                       const float* __restrict__ bias) {
-  const int cv = C >> 2;
-  const size_t total = (size_t)B * H * W * cv;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c4 = (int)(i % cv) * 4;
-    size_t p = i / cv;
-    const int ox = (int)(p % W);
-    p /= W;
-    const int oy = (int)(p % H);
-    const int b = (int)(p / H);
-    f32x4 acc = *(const f32x4*)(bias + c4);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sw = (float*)smem;                 // [49][32]
+  float* sx = sw + 49 * DW_CB;              // [DW_TH + 6][W + 6][DW_PS]  (zero halo of 3 columns on both sides)
+  const int cblocks = C / DW_CB, rtiles = (H + DW_TH - 1) / DW_TH;
+  int bid = blockIdx.x;
+  const int cb = (bid % cblocks) * DW_CB;
+  bid /= cblocks;
+  const int oy0 = (bid % rtiles) * DW_TH, b = bid / rtiles;
+  const int WP = W + 6;
+  for (int i = threadIdx.x; i < 49 * (DW_CB / 4); i += 256) {
+    const int t = i / (DW_CB / 4), v = i - t * (DW_CB / 4);
+    *(f32x4*)(sw + t * DW_CB + v * 4) = *(const f32x4*)(w + (size_t)t * C + cb + v * 4);
+  }
+  for (int i = threadIdx.x; i < (DW_TH + 6) * WP * (DW_CB / 4); i += 256) {
+    const int v = i % (DW_CB / 4);
+    const int p = i / (DW_CB / 4);
+    const int r = p / WP, cx = p - r * WP;
+    const int iy = oy0 - 3 + r, ix = cx - 3;
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = *(const f32x4*)(x + (((size_t)b * H + iy) * W + ix) * C + cb + v * 4);
+    *(f32x4*)(sx + (size_t)(r * WP + cx) * DW_PS + v * 4) = val;
+  }
+  __syncthreads();
+  const int v = threadIdx.x & 7, pl = threadIdx.x >> 3;  // 8 channel quads x 32 run lanes
+  const int runs_per_row = (W + 3) / 4;
+  const f32x4 bv = *(const f32x4*)(bias + cb + v * 4);
+  for (int run = pl; run < DW_TH * runs_per_row; run += 32) {
+    const int ry = run / runs_per_row, ox0 = (run - ry * runs_per_row) * 4;
+    if (oy0 + ry >= H) break;
+    f32x4 acc[4] = {bv, bv, bv, bv};
+#pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
-      const int iy = oy - 3 + ky;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < 7; ++kx) {
-        const int ix = ox - 3 + kx;
-        if (ix < 0 || ix >= W) continue;
-        const f32x4 v = *(const f32x4*)(x + (((size_t)b * H + iy) * W + ix) * C + c4);
-        const f32x4 wv = *(const f32x4*)(w + (size_t)(ky * 7 + kx) * C + c4);
-        acc += v * wv;
-      }
+      const float* row = sx + (size_t)((ry + ky) * WP + ox0) * DW_PS + v * 4;
+      f32x4 in[10], wk[7];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) in[i] = (ox0 + i < WP) ? *(const f32x4*)(row + i * DW_PS) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) wk[kx] = *(const f32x4*)(sw + (ky * 7 + kx) * DW_CB + v * 4);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) acc[o] += in[o + kx] * wk[kx];
     }
-    *(f32x4*)(y + i * 4) = acc;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (ox0 + o < W) *(f32x4*)(y + (((size_t)b * H + oy0 + ry) * W + ox0 + o) * C + cb + v * 4) = acc[o];
   }
 }
 
@@ -418,8 +447,13 @@ extern "C" int vdn_mask_down2(const float* in, float* out, int B, int H, int W, 
 extern "C" int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C, const float* w, const float* bias,
                            vdn_stream stream) {
   if (!x || !y || !w || !bias || B <= 0 || H <= 0 || W <= 0 || C <= 0) return VDN_EINVAL;
-  if (C & 3) return VDN_EALIGN;
-  hipLaunchKernelGGL(dwconv7_kernel, dim3(grid_for((size_t)B * H * W * (C >> 2), 16384)), dim3(256), 0,
+  if (C % DW_CB) return VDN_EALIGN;
+  const size_t lds = ((size_t)49 * DW_CB + (size_t)(DW_TH + 6) * (W + 6) * DW_PS) * sizeof(float);
+  if (lds > 160 * 1024) return VDN_EUNSUPPORTED;  // W <= 73
+  static const bool lds_ok = hipFuncSetAttribute((const void*)dwconv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 160 * 1024) == hipSuccess;
+  (void)lds_ok;
+  hipLaunchKernelGGL(dwconv7_kernel, dim3(B * ((H + DW_TH - 1) / DW_TH) * (C / DW_CB)), dim3(256), lds,
                      (hipStream_t)stream, x, y, B, H, W, C, w, bias);
   VDN_CHECK_LAUNCH();
   return VDN_OK;

@@ -12,6 +12,7 @@ F16, BF16, F32, NONE = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 A_PLAIN, A_CONV3X3 = 0, 1
 ST_PLAIN, ST_HEADS, ST_CONVT, ST_GEGLU = 0, 1, 2, 3
+PACK_LINEAR, PACK_CONV3X3, PACK_CONV3X3_TAPS, PACK_CONVT, PACK_GEGLU, PACK_ROPE = 0, 1, 2, 3, 4, 5
 
 i32, vp, fp = C.c_int32, C.c_void_p, C.c_void_p
 
@@ -70,6 +71,8 @@ EXPORTS = {
                                 C.c_int, vp, vp, C.c_int, fp, vp]),
     "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_float, vp]),
+    "vdn_flash_attn_set_pv_products": (C.c_int, [C.c_int]),
+    "vdn_flash_attn_get_pv_products": (C.c_int, []),
     "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp,
                                 C.c_int, vp]),
@@ -80,6 +83,14 @@ EXPORTS = {
     "vdn_bicubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "vdn_add_vec": (C.c_int, [fp, fp, C.c_float, fp, C.c_int, C.c_int, vp]),
     "vdn_head_out": (C.c_int, [C.c_int, vp, vp, fp, C.c_float, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_depth_tail": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, fp, fp, C.c_float, fp,
+                                 C.c_int, C.c_int, C.c_int, vp]),
+    "vdn_pack_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vdn_pack_ldb": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vdn_pack_weight": (C.c_int, [C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    "vdn_pack_bias": (C.c_int, [C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, vp]),
+    "vdn_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "vdn_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vdn_mask_down1": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_mask_down2": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_dwconv7": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, vp]),

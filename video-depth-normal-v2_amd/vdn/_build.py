@@ -11,7 +11,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libvdn_hip.so")
 SOURCES = ["gemm_big_f16.hip", "gemm_big_bf16.hip", "gemm_small_f16.hip", "gemm_small_bf16.hip", "gemm.hip", "attn.hip",
-           "norm.hip", "spatial.hip", "stitch.hip", "refine.hip"]
+           "norm.hip", "spatial.hip", "tail.hip", "pack.hip", "stitch.hip", "refine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

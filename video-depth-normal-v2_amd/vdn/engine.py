@@ -10,6 +10,7 @@ Every function cites the reference code it stands for (paths relative to the ref
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -253,6 +254,10 @@ class DPTEngine:
                                wo=pack.conv1x1(f.out_conv.weight, h), bo=pack.f32(f.out_conv.bias))
         self.oc1 = (pack.conv3x3(s.output_conv1.weight, h), pack.f32(s.output_conv1.bias))
         self.oc2 = (pack.conv3x3(s.output_conv2[0].weight, h), pack.f32(s.output_conv2[0].bias))
+        # fused tail (csrc/tail.hip): needs split planes, 32 output channels and 32-channel input blocks
+        w2 = s.output_conv2[0].weight
+        fused = h.split and w2.shape[0] == 32 and w2.shape[1] % 32 == 0 and not os.environ.get("VDN_TAIL_UNFUSED")  # A/B switch
+        self.oc2_taps = pack.conv3x3_taps(w2, h) if fused else None
         self.w_last = pack.f32(s.output_conv2[2].weight).reshape(-1)
         self.b_last = float(s.output_conv2[2].bias.detach().float().item())
         self.temporal = None
@@ -337,10 +342,13 @@ class DPTEngine:
         p1 = self._fusion(1, Bf, s1, s0, p2, r1)
         o1 = self._conv3(p1, self.oc1[0], Bf, s0[0], s0[1], F, F // 2, "out1", bias=self.oc1[1])
         H, W = ph * PATCH, pw * PATCH
+        depth = rt.fbuf("depth", (Bf, H, W))
+        if self.oc2_taps is not None:  # resize -> conv3x3 + ReLU -> conv1x1 (+ ReLU) without leaving the chip
+            rt.depth_tail(o1, self.oc2_taps, self.oc2[1], self.w_last, self.b_last, depth, Bf, s0[0], s0[1], F // 2, H, W, relu)
+            return depth
         up = rt.hbuf("out_up", (Bf * H * W, F // 2))
         rt.upsample(o1, up, Bf, s0[0], s0[1], H, W, F // 2)
         o2 = self._conv3(up, self.oc2[0], Bf, H, W, F // 2, 32, "out2", bias=self.oc2[1], act=RELU)
-        depth = rt.fbuf("depth", (Bf, H, W))
         rt.head_out(o2, self.w_last, self.b_last, depth, Bf * H * W, 32, relu)
         return depth
 

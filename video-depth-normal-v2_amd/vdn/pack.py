@@ -1,4 +1,5 @@
-"""One-time weight packing into the layouts the kernels read (done on the device, at model build).
+"""One-time weight packing into the layouts the kernels read: thin callers of the C-ABI packers
+(include/vdn.h: vdn_pack_weight / vdn_pack_bias, csrc/pack.hip), run on the device at model build.
 
 All GEMM weights become half [N, ldb] with K contiguous and zero padded to a multiple of 64:
   linear    [N,K]                 -> as is
@@ -24,23 +25,63 @@ class Prec:
         self.dtype, self.split = dtype, split
 
 
+def _prec(half) -> Prec:
+    return half if isinstance(half, Prec) else Prec(half, False)
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _pack_into(kind: int, w: torch.Tensor, d0: int, d1: int, d2: int, out, row0: int = 0):
+    """vdn_pack_weight (include/vdn.h) of one fp32 parameter into rows [row0, row0 + rows) of the planes `out`."""
+    from . import _abi as abi
+    wf = w.detach().float().contiguous()
+    if not wf.is_cuda:
+        raise abi.VdnError("weights are packed on the device by libvdn_hip.so: move the module to the GPU first")
+    ldb = out.hi.shape[1]
+    off = row0 * ldb * out.hi.element_size()
+    dt = abi.F16 if out.hi.dtype == torch.float16 else abi.BF16
+    abi.check(abi.lib.vdn_pack_weight(dt, kind, wf.data_ptr(), d0, d1, d2, out.hi.data_ptr() + off,
+                                      None if out.lo is None else out.lo.data_ptr() + off, ldb, _stream(wf)), "vdn_pack_weight")
+    return out
+
+
+def _planes(kind: int, d0: int, d1: int, d2: int, half, device, rows=None):
+    from . import _abi as abi
+    from .runtime import HL
+    prec = _prec(half)
+    r, ldb = abi.lib.vdn_pack_rows(kind, d0, d1, d2), abi.lib.vdn_pack_ldb(kind, d0, d1, d2)
+    if r < 0 or ldb < 0:
+        raise ValueError(f"vdn_pack: unsupported shape for layout {kind}: {(d0, d1, d2)}")
+    hi = torch.empty((rows or r, ldb), dtype=prec.dtype, device=device)
+    return HL(hi, torch.empty_like(hi) if prec.split else None)
+
+
+def _pack(kind: int, w: torch.Tensor, d0: int, d1: int, d2: int, half):
+    return _pack_into(kind, w, d0, d1, d2, _planes(kind, d0, d1, d2, half, w.device))
+
+
+def _pack_bias(kind: int, b: torch.Tensor, d0: int, d1: int, d2: int) -> torch.Tensor:
+    from . import _abi as abi
+    bf = b.detach().float().contiguous()
+    out = torch.empty((abi.lib.vdn_pack_rows(kind, d0, d1, d2),), dtype=torch.float32, device=bf.device)
+    abi.check(abi.lib.vdn_pack_bias(kind, bf.data_ptr(), d0, d1, d2, out.data_ptr(), _stream(bf)), "vdn_pack_bias")
+    return out
+
+
 def _pad_k(w2: torch.Tensor, half) -> "HL":
     """f32 [N,K] -> HL of half [N, ceil64(K)] (zero tail). `half` is a Prec or a bare dtype."""
-    from .runtime import HL
-    prec = half if isinstance(half, Prec) else Prec(half, False)
-    n, k = w2.shape
-    kp = (k + 63) // 64 * 64
-    full = torch.zeros((n, kp), dtype=torch.float32, device=w2.device)
-    full[:, :k] = w2
-    return HL.from_float(full, prec.dtype, prec.split)
+    from . import _abi as abi
+    return _pack(abi.PACK_LINEAR, w2, w2.shape[0], w2.shape[1], 0, half)
 
 
 def linear(w: torch.Tensor, half) -> torch.Tensor:
-    return _pad_k(w.detach().float(), half)
+    return _pad_k(w, half)
 
 
 def conv1x1(w: torch.Tensor, half) -> torch.Tensor:
-    return _pad_k(w.detach().float().reshape(w.shape[0], w.shape[1]), half)
+    return _pad_k(w.reshape(w.shape[0], w.shape[1]), half)
 
 
 def conv_korder(ci: int) -> int:
@@ -50,71 +91,51 @@ def conv_korder(ci: int) -> int:
 
 
 def conv3x3(w: torch.Tensor, half) -> torch.Tensor:
+    from . import _abi as abi
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3 and ci % 8 == 0, w.shape
-    wf = w.detach().float()
-    if conv_korder(ci):
-        # [co, c64, 64, ky, kx] -> [co, c64, ky, kx, 64]
-        wk = wf.reshape(co, ci // 64, 64, 3, 3).permute(0, 1, 3, 4, 2).reshape(co, 9 * ci)
-    else:
-        wk = wf.permute(0, 2, 3, 1).reshape(co, 9 * ci)
-    return _pad_k(wk, half)
+    return _pack(abi.PACK_CONV3X3, w, co, ci, 0, half)
+
+
+def conv3x3_taps(w: torch.Tensor, half) -> torch.Tensor:
+    """[Co,Ci,3,3] -> [Co, (ky,kx,ci)] always tap-major (the fused depth tail, csrc/tail.hip, walks K tap by tap)."""
+    from . import _abi as abi
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and ci % 32 == 0, w.shape
+    return _pack(abi.PACK_CONV3X3_TAPS, w, co, ci, 0, half)
 
 
 def conv_transpose(w: torch.Tensor, b: torch.Tensor, half) -> Tuple[torch.Tensor, torch.Tensor]:
+    from . import _abi as abi
     ci, co, k, k2 = w.shape
     assert k == k2
-    wg = w.detach().float().permute(2, 3, 1, 0).reshape(k * k * co, ci)  # n = (ky*k+kx)*co + c
-    bias = b.detach().float().repeat(k * k).contiguous()
-    return _pad_k(wg, half), bias
+    return _pack(abi.PACK_CONVT, w, ci, co, k, half), _pack_bias(abi.PACK_CONVT, b, ci, co, k)  # n = (ky*k+kx)*co + c
 
 
 def patch_embed(w: torch.Tensor, half) -> torch.Tensor:
-    c = w.shape[0]
-    return _pad_k(w.detach().float().reshape(c, -1), half)  # 588 -> 640
-
-
-def _geglu_perm(n_half: int, device) -> torch.Tensor:
-    assert n_half % 16 == 0
-    t = torch.arange(n_half // 16, device=device)
-    r = torch.arange(16, device=device)
-    h_rows = (t[:, None] * 16 + r[None, :])              # [blocks,16]
-    g_rows = h_rows + n_half
-    return torch.stack([h_rows, g_rows], dim=1).reshape(-1)  # block t: 16 h rows then 16 gate rows
+    return _pad_k(w.reshape(w.shape[0], -1), half)  # 588 -> 640
 
 
 def geglu(w: torch.Tensor, b: torch.Tensor, half) -> Tuple[torch.Tensor, torch.Tensor]:
-    n = w.shape[0]
-    perm = _geglu_perm(n // 2, w.device)
-    return _pad_k(w.detach().float()[perm], half), b.detach().float()[perm].contiguous()
-
-
-def rope_perm(c: int, device) -> torch.Tensor:
-    """Row permutation for a [C, K] projection whose output is RoPE-rotated per 64-wide head:
-    packed position p of head h holds original row h*64 + src(p)."""
-    p = torch.arange(64, device=device)
-    blk, r = p // 16, p % 16
-    pair = (blk // 2) * 16 + r
-    src = 2 * pair + (blk % 2)
-    heads = torch.arange(c // 64, device=device)
-    return (heads[:, None] * 64 + src[None, :]).reshape(-1)
+    from . import _abi as abi
+    n, k = w.shape
+    return _pack(abi.PACK_GEGLU, w, n, k, 0, half), _pack_bias(abi.PACK_GEGLU, b, n, k, 0)
 
 
 def cat_proj(ws, bs, ropes, half) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Concatenate projections along N; splits flagged in `ropes` get the pair-split row order."""
-    wl, bl = [], []
+    from . import _abi as abi
+    k = ws[0].shape[1]
+    total = sum(w.shape[0] for w in ws)
+    out = _planes(abi.PACK_LINEAR, total, k, 0, half, ws[0].device)
+    bl, row0 = [], 0
     for w, b, rp in zip(ws, bs, ropes):
-        w = w.detach().float()
-        b = None if b is None else b.detach().float()
-        if rp:
-            perm = rope_perm(w.shape[0], w.device)
-            w = w[perm]
-            b = None if b is None else b[perm]
-        wl.append(w)
-        bl.append(b)
-    wcat = torch.cat(wl, dim=0)
+        kind = abi.PACK_ROPE if rp else abi.PACK_LINEAR
+        _pack_into(kind, w, w.shape[0], k, 0, out, row0)
+        bl.append(None if b is None else _pack_bias(kind, b, w.shape[0], k, 0))
+        row0 += w.shape[0]
     bias = None if bl[0] is None else torch.cat(bl, dim=0).contiguous()
-    return _pad_k(wcat, half), bias
+    return out, bias
 
 
 def rope_table(side_y: int, side_x: int, dim: int = 64, theta: float = 10000.0, device=None) -> torch.Tensor:
