@@ -280,12 +280,14 @@ int vdn_refine_finish(const float* scaled, const float* depth, float w, float b,
                       size_t n, vdn_stream stream);
 
 /* Fused depth tail (depth_anything_v2/dpt.py:146-151; video_depth_anything/dpt_temporal.py:106-111 runs the same ops
- * in micro-batches): bilinear resize (align_corners=True) of the split-plane NHWC map x [B, IH, IW, C] to (OH, OW),
- * Conv3x3(C -> 32, pad 1) + bias2 + ReLU, Conv1x1(32 -> 1) + b1 [+ ReLU when relu != 0] -> depth f32 [B, OH, OW].
- * The up-sampled map and the 32-channel map stay on chip. w / w_lo: split planes [32, ldb] with K = tap * C + ci
- * (tap = 3 ky + kx; vdn.pack.conv3x3_taps), ldb >= 9 C; C a multiple of 32; 3 MFMA products per term.          */
-int vdn_depth_tail(int dt, const void* x, const void* x_lo, int B, int IH, int IW, int C, const void* w, const void* w_lo,
-                   int ldb, const float* bias2, const float* w1, float b1, float* depth, int OH, int OW, int relu,
+ * in micro-batches): bilinear resize (align_corners=True) of the fp32 NHWC map x [B, IH, IW, C] (output_conv1's result,
+ * written as ONE fp32 plane) to (OH, OW), Conv3x3(C -> 32, pad 1) + bias2 + ReLU, Conv1x1(32 -> 1) + b1 [+ ReLU when
+ * relu != 0] -> depth f32 [B, OH, OW]. The up-sampled map and the 32-channel map stay on chip. w / w_lo: split planes
+ * [32, ldb] with K = tap * C + ci (tap = 3 ky + kx; VDN_PACK_CONV3X3_TAPS), ldb >= 9 C; C a multiple of 32; `dt` is
+ * the 16-bit type of the weight planes and of the on-chip up-sampled fragments; 3 MFMA products per term. The scale
+ * (IH-1)/(OH-1) must be <= 10/17 (a 13 x 13 source patch covers a tile's halo): VDN_EUNSUPPORTED otherwise.           */
+int vdn_depth_tail(int dt, const float* x, int B, int IH, int IW, int C, const void* w, const void* w_lo, int ldb,
+                   const float* bias2, const float* w1, float b1, float* depth, int OH, int OW, int relu,
                    vdn_stream stream);
 
 /* One-time weight packing ON THE DEVICE, so that a host in any language can feed the library from the reference's

@@ -876,11 +876,12 @@ def test_depth_tail_fused_against_fp64_and_unfused(rt3, B, IH, IW, C, OH, OW):
     mid = F.relu(F.conv2d(up, w2.double(), b2.double(), padding=1))
     ref = (mid * w1.double().reshape(1, 32, 1, 1)).sum(1) + b1
     xa = rt3.to_half(x.reshape(-1, C).to(DEV))
+    xf = x.reshape(-1, C).to(DEV).contiguous()
     wt = pack.conv3x3_taps(w2.to(DEV), rt3.prec)
     d = torch.empty(B, OH, OW, device=DEV)
-    rt3.depth_tail(xa, wt, b2.to(DEV), w1.to(DEV), b1, d, B, IH, IW, C, OH, OW, relu=False)
+    rt3.depth_tail(xf, wt, b2.to(DEV), w1.to(DEV), b1, d, B, IH, IW, C, OH, OW, relu=False)
     close(d, ref.float(), 2e-5)  # the zero-mean 1x1 weights cancel ~4x: 2e-5 of the output is ~5e-6 of the conv sums
-    rt3.depth_tail(xa, wt, b2.to(DEV), w1.to(DEV), b1, d, B, IH, IW, C, OH, OW, relu=True)
+    rt3.depth_tail(xf, wt, b2.to(DEV), w1.to(DEV), b1, d, B, IH, IW, C, OH, OW, relu=True)
     close(d, F.relu(ref).float(), 2e-5)
     # the unfused path: upsample kernel -> implicit-GEMM conv -> head_out
     upb = rt3.hbuf(f"t_tail_up{C}_{OH}", (B * OH * OW, C))
@@ -891,7 +892,7 @@ def test_depth_tail_fused_against_fp64_and_unfused(rt3, B, IH, IW, C, OH, OW):
              conv=dict(B=B, H=OH, W=OW, C=C, OH=OH, OW=OW, stride=1))
     d2 = torch.empty(B, OH, OW, device=DEV)
     rt3.head_out(o2, w1.to(DEV), b1, d2, B * OH * OW, 32, relu=True)
-    close(d, d2, 1e-5)
+    close(d, d2, 3e-5)  # two fp32 summation orders, each ~5e-6 from fp64, through the cancelling 1x1 weights
 
 
 def test_pack_weight_abi_against_torch_layouts(rt3):

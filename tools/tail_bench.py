@@ -8,7 +8,7 @@ from vdn.runtime import Runtime
 from vdn import pack
 rt = Runtime(torch.device("cuda:0"), torch.float16, split=True)
 B, IH, C, OH = 8, 296, 128, 518
-x = rt.to_half(torch.randn(B * IH * IH, C, device="cuda"))
+x = torch.randn(B * IH * IH, C, device="cuda")
 w = pack.conv3x3_taps(torch.randn(32, C, 3, 3, device="cuda") / math.sqrt(9 * C), rt.prec)
 b2, w1 = torch.randn(32, device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.3
 d = torch.empty(B, OH, OH, device="cuda")

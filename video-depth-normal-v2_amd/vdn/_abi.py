@@ -83,7 +83,7 @@ EXPORTS = {
     "vdn_bicubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "vdn_add_vec": (C.c_int, [fp, fp, C.c_float, fp, C.c_int, C.c_int, vp]),
     "vdn_head_out": (C.c_int, [C.c_int, vp, vp, fp, C.c_float, fp, C.c_int, C.c_int, C.c_int, vp]),
-    "vdn_depth_tail": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, fp, fp, C.c_float, fp,
+    "vdn_depth_tail": (C.c_int, [C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, fp, fp, C.c_float, fp,
                                  C.c_int, C.c_int, C.c_int, vp]),
     "vdn_pack_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "vdn_pack_ldb": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -266,9 +266,10 @@ class DPTEngine:
             self.temporal = [TemporalEngine(rt, mod.motion_modules[i], chans[i], i) for i in range(4)]
 
     # -- helpers
-    def _conv3(self, x, w, Bf, H, W, Cin, Cout, name, *, stride=1, bias=None, relu_a=False, act=0, res1=None, res2=None):
+    def _conv3(self, x, w, Bf, H, W, Cin, Cout, name, *, stride=1, bias=None, relu_a=False, act=0, res1=None, res2=None,
+               f32_out=False):
         OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-        out = self.rt.hbuf(name, (Bf * OH * OW, Cout))
+        out = (self.rt.fbuf if f32_out else self.rt.hbuf)(name, (Bf * OH * OW, Cout))
         self.rt.gemm(x, w, Bf * OH * OW, Cout, 9 * Cin, out=out, bias=bias, act=act, relu_a=relu_a, res1=res1, res2=res2,
                      conv=dict(B=Bf, H=H, W=W, C=Cin, OH=OH, OW=OW, stride=stride))
         return out
@@ -340,12 +341,16 @@ class DPTEngine:
         p2 = self._fusion(2, Bf, s2, s1, p3, r2)
         s0 = (2 * s1[0], 2 * s1[1])
         p1 = self._fusion(1, Bf, s1, s0, p2, r1)
-        o1 = self._conv3(p1, self.oc1[0], Bf, s0[0], s0[1], F, F // 2, "out1", bias=self.oc1[1])
         H, W = ph * PATCH, pw * PATCH
         depth = rt.fbuf("depth", (Bf, H, W))
-        if self.oc2_taps is not None:  # resize -> conv3x3 + ReLU -> conv1x1 (+ ReLU) without leaving the chip
+        sy, sx = (s0[0] - 1) / max(H - 1, 1), (s0[1] - 1) / max(W - 1, 1)
+        if self.oc2_taps is not None and int(17 * sy) + 3 <= 13 and int(17 * sx) + 3 <= 13:
+            # resize -> conv3x3 + ReLU -> conv1x1 (+ ReLU) without leaving the chip (the scale is 8/14 for every DPT head);
+            # output_conv1 then writes ONE fp32 plane, which is what the fused kernel interpolates from
+            o1 = self._conv3(p1, self.oc1[0], Bf, s0[0], s0[1], F, F // 2, "out1_f32", bias=self.oc1[1], f32_out=True)
             rt.depth_tail(o1, self.oc2_taps, self.oc2[1], self.w_last, self.b_last, depth, Bf, s0[0], s0[1], F // 2, H, W, relu)
             return depth
+        o1 = self._conv3(p1, self.oc1[0], Bf, s0[0], s0[1], F, F // 2, "out1", bias=self.oc1[1])
         up = rt.hbuf("out_up", (Bf * H * W, F // 2))
         rt.upsample(o1, up, Bf, s0[0], s0[1], H, W, F // 2)
         o2 = self._conv3(up, self.oc2[0], Bf, H, W, F // 2, 32, "out2", bias=self.oc2[1], act=RELU)

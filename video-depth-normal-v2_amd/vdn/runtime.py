@@ -279,12 +279,12 @@ class Runtime:
     def add_vec(self, x, vec, alpha: float, y, rows: int, Cn: int):
         self._launch(abi.lib.vdn_add_vec, x.data_ptr(), vec.data_ptr(), alpha, y.data_ptr(), rows, Cn)
 
-    def depth_tail(self, x: HL, w: HL, bias2, w1, b1: float, depth, B: int, IH: int, IW: int, Cn: int, OH: int, OW: int,
-                   relu: bool):
-        """resize(align_corners) -> conv3x3 + ReLU -> conv1x1 [+ ReLU] in one launch (split-plane modes only)."""
-        assert x.lo is not None and w.lo is not None and w.hi.shape[0] == 32
-        self._launch(abi.lib.vdn_depth_tail, self.dt, x.hi.data_ptr(), x.lo.data_ptr(), B, IH, IW, Cn, w.hi.data_ptr(),
-                     w.lo.data_ptr(), w.hi.shape[1], bias2.data_ptr(), w1.data_ptr(), b1, depth.data_ptr(), OH, OW, int(relu))
+    def depth_tail(self, x: torch.Tensor, w: HL, bias2, w1, b1: float, depth, B: int, IH: int, IW: int, Cn: int, OH: int,
+                   OW: int, relu: bool):
+        """resize(align_corners) -> conv3x3 + ReLU -> conv1x1 [+ ReLU] in one launch; x f32 NHWC (split-plane modes only)."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and w.lo is not None and w.hi.shape[0] == 32
+        self._launch(abi.lib.vdn_depth_tail, self.dt, x.data_ptr(), B, IH, IW, Cn, w.hi.data_ptr(), w.lo.data_ptr(),
+                     w.hi.shape[1], bias2.data_ptr(), w1.data_ptr(), b1, depth.data_ptr(), OH, OW, int(relu))
 
     def head_out(self, feat, w, bias: float, depth, M: int, Cn: int, relu: bool):
         feat, fl = _hl(feat)
