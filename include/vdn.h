@@ -127,6 +127,11 @@ typedef struct vdn_gemm_desc {
   void* splitk_ws;
   int64_t splitk_ws_bytes;
   int32_t ksplit;
+  /* HEADS, split-plane mode, VDN_F16 only: optional 8-bit planes of a token-major split s (Q / K) for the attention
+   * kernel's cross terms (vdn_flash_attn Q8 / K8): u8 [Bt, heads, tpad, 128], per token 64 bytes of e5m2(v) followed by
+   * 64 bytes of e5m2((v - hi(v)) * 2^10), same token mapping as dst[s]. NULL = not written. Must be NULL for
+   * transposed splits.                                                                                            */
+  void* dst8[3];
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
@@ -167,10 +172,13 @@ int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, cons
  *   Q  half [BH, nq_pad, 64] (rows >= nq never read), K half [BH, nk_pad, 64],
  *   Vt half [BH, 64, nk_pad] (dim-major; columns >= nk must be finite), nk_pad % 64 == 0.
  * Scores never touch HBM. Replaces dinov2_layers/attention.py:53-59 and
- * F.scaled_dot_product_attention at sam2/modeling/sam/transformer.py:306.                        */
+ * F.scaled_dot_product_attention at sam2/modeling/sam/transformer.py:306.
+ *   Q8 / K8 (both or neither; split fp16 planes only): the 8-bit planes vdn_gemm wrote through dst8
+ *   (u8 [BH, n_pad, 128]); the two cross terms K_hi Q_lo^T + K_lo Q_hi^T of the scores then run on the block-scaled
+ *   8-bit MFMA (e5m2, 2.3x the fp16 rate) instead of two fp16 products; logits stay within ~1e-5. NULL = 3 fp16 products. */
 int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
-                   const void* K_lo, const void* Vt_lo, void* out_lo, int B, int H, int nq, int nq_pad, int nk,
-                   int nk_pad, float scale, vdn_stream stream);
+                   const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, int B, int H, int nq,
+                   int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
 /* Split-plane mode only: MFMA products per P V term. 2 (default): the softmax weights, born in registers, are
  * rounded once to 16 bits and the row sum uses the same rounded weights (O = sum p~ V / sum p~, V at 21 bits): each
  * weight is off by <= 2^-11 relative, common factors cancel. 3: P is split into hi / lo planes too (every output

@@ -469,8 +469,18 @@ def test_x3_heads_rope_and_flash(rt3):
     qd, kd = rt3.hbuf("t_q", (B * Hh, tp, 64), zero=True), rt3.hbuf("t_k", (B * Hh, tp, 64), zero=True)
     vd = rt3.hbuf("t_v", (B * Hh, 64, tp), zero=True)
     cs = pack.rope_table(side, side, 64, device=DEV)
+    q8, k8 = rt3.qk8("t_q8", B * Hh, tp), rt3.qk8("t_k8", B * Hh, tp)
     rt3.gemm(rt3.to_half(a.to(DEV)), wp, B * P, 3 * C, C, bias=bp, store=_abi.ST_HEADS,
-             heads=dict(dst=[qd, kd, vd], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=tp))
+             heads=dict(dst=[qd, kd, vd], dst8=[q8, k8, None], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P,
+                        heads=Hh, tokens=P, tpad=tp))
+    # the 8-bit planes the epilogue wrote: e5m2(value) | e5m2(remainder * 2^10) per token
+    for plane8, planes in ((q8, qd), (k8, kd)):
+        want_hi = planes.float()[:, :P].to(torch.float8_e5m2).view(torch.uint8)
+        want_lo = (planes.lo.float()[:, :P] * 1024.0).to(torch.float8_e5m2).view(torch.uint8)
+        got = plane8[:, :P]
+        # e5m2(value) is rounded from the fp32 accumulator, the check rounds hi + lo (21 bits): ties may differ by one code
+        assert (got[..., :64].int() - want_hi.int()).abs().max() <= 1 and (got[..., :64] != want_hi).float().mean() < 1e-3
+        assert torch.equal(got[..., 64:], want_lo)
     close(qd.float().reshape(B, Hh, tp, 64)[:, :, :P], q, 5e-6)
     close(vd.float().reshape(B, Hh, 64, tp)[:, :, :, :P], v.transpose(2, 3), 5e-6)
     out = rt3.hbuf("t_o", (B * P, C))
@@ -481,18 +491,22 @@ def test_x3_heads_rope_and_flash(rt3):
         finally:
             _abi.lib.vdn_flash_attn_set_pv_products(2)
         close(out.float().reshape(B, P, C), ref, tol)
+    rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125, q8=q8, k8=k8)  # score cross terms on the 8-bit MFMA
+    close(out.float().reshape(B, P, C), ref, 3e-4)
 
 
-@pytest.mark.parametrize("pv,tol", [(3, 1e-5), (2, 3e-4)])
+@pytest.mark.parametrize("pv,tol,qk8", [(3, 1e-5, False), (2, 3e-4, False), (2, 3e-4, True)])
 @pytest.mark.parametrize("nq,nk,gain", [(150, 200, 1.0), (1370, 1370, 1.0), (37, 64, 1.0), (70, 128, 1.0), (100, 130, 1.0),
                                         (129, 777, 6.0)])
-def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol):
+def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8):
     """1 / 2 / 3 / many key tiles (the software pipeline's prologue, peeled first and last iterations), ragged
     last tile; gain 6 makes row maxima jump by far more than the lazy-rescale threshold between tiles.
     pv = 3: P carried as hi/lo planes, fp32-faithful (1e-5 against fp64). pv = 2 (the default): every softmax weight
     rounded once to fp16 and normalised by the sum of the rounded weights: <= 2^-11 relative per weight, which on these
     independent random V rows (the worst case: nothing in common to cancel) gives ~1e-4; end to end it is invisible
-    (tests/test_gpu_e2e.py prints 4e-6..1e-5 either way)."""
+    (tests/test_gpu_e2e.py prints 4e-6..1e-5 either way). qk8: the score cross terms K_hi Q_lo^T + K_lo Q_hi^T on the
+    block-scaled e5m2 MFMA from the 8-bit planes (built here as the projection epilogue builds them); its own error
+    (~1e-5 of a logit) disappears under the pv = 2 rounding."""
     from vdn import _abi
     from vdn.runtime import ceil_to
     _abi.lib.vdn_flash_attn_set_pv_products(pv)
@@ -509,12 +523,18 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol):
     vd.hi[:, :, :nk] = s.hi
     vd.lo[:, :, :nk] = s.lo
     out = rt3.hbuf("t2_o", (B * nq, H * 64))
+    q8 = k8 = None
+    if qk8:
+        def planes8(t):  # HL [BH, pad, 64] -> u8 [BH, pad, 128]
+            return torch.cat([t.float().to(torch.float8_e5m2).view(torch.uint8),
+                              (t.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)], dim=-1).contiguous()
+        q8, k8 = planes8(qd), planes8(kd)
     try:
-        rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
+        rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125, q8=q8, k8=k8)
         close(out.float().reshape(B, nq, H * 64), ref, tol)
         first = (out.hi.clone(), out.lo.clone())
         for _ in range(3):  # bitwise repeatable (race screen for the LDS ring / counted waits)
-            rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125)
+            rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125, q8=q8, k8=k8)
             assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
     finally:
         _abi.lib.vdn_flash_attn_set_pv_products(2)

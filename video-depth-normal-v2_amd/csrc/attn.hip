@@ -17,6 +17,12 @@
 //   SAME rounded p~ (one v_dot2 per pair), so O / l is an exact convex combination of the (21-bit) V rows with
 //   weights p~ / sum p~: the rounding perturbs each weight by <= 2^-11 relative and any part of it common to a
 //   row cancels in the normalisation (DESIGN.md §3 has the measured end-to-end effect).
+//   QK8 (with PV2, fp16 only): the two CROSS terms of S^T = K Q^T run on the block-scaled 8-bit MFMA
+//   (v_mfma_scale_f32_32x32x64_f8f6f4, e5m2 operands, K = 64 = the whole head dimension in one instruction, 2.3x the
+//   fp16 rate measured): S^T = K_hi Q_hi^T [4 fp16 MFMAs] + K8 (Q_lo8)^T 2^-10 + K_lo8 (Q8)^T 2^-10 [2 MFMAs], where
+//   X8 = e5m2(X) and X_lo8 = e5m2((X - X_hi) 2^10) are written by the projection GEMM's epilogue (vdn_gemm_desc.dst8)
+//   and the 2^-10 is the MFMA's E8M0 scale operand. A cross term is 2^-11 of the product, so the 3-bit e5m2 significand
+//   leaves 2^-14 per term: logits good to ~1e-5 (tools/micro/mfma_scale_probe.hip pins layout, scale and rate).
 //
 // temporal_attn_kernel — <= 32 frames per (pixel, head): one wave per sequence, fragments loaded
 //   straight from global memory (no LDS), same accumulator-as-operand chaining.
@@ -56,7 +62,9 @@ __device__ __forceinline__ void for_each_slot(F& f) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int DT, bool SPLIT, bool PV2>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int DT, bool SPLIT, bool PV2, bool QK8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_kernel(const typename Half<DT>::T* __restrict__ Q,
                                                          const typename Half<DT>::T* __restrict__ K,
                                                          const typename Half<DT>::T* __restrict__ Vt,
@@ -64,8 +72,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                          const typename Half<DT>::T* __restrict__ Ql,
                                                          const typename Half<DT>::T* __restrict__ Kl,
                                                          const typename Half<DT>::T* __restrict__ Vtl,
-                                                         typename Half<DT>::T* __restrict__ outl, int H, int nq,
-                                                         int nq_pad, int nk, int nk_pad, float scale_log2) {
+                                                         typename Half<DT>::T* __restrict__ outl,
+                                                         const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ K8,
+                                                         int H, int nq, int nq_pad, int nk, int nk_pad, float scale_log2) {
+  static_assert(!QK8 || (SPLIT && PV2 && DT == VDN_F16), "8-bit cross terms: split fp16 planes, 2-product P V");
   using HT = Half<DT>;
   using T = typename HT::T;
   using V8 = typename HT::V8;
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 ks + 8 h + j]
   V8 qf[4], ql[4];
+  i32x8 q8h, q8l;  // QK8: B operands of the 32x32x64 8-bit MFMA: Q8[q][32 h + j], j = 0..31
   {
     int q = q0 + r;
     q = q < nq ? q : nq - 1;
@@ -93,7 +104,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qf[ks] = *(const V8*)(Q + qo + 16 * ks);
-      if constexpr (SPLIT) ql[ks] = *(const V8*)(Ql + qo + 16 * ks);
+      if constexpr (SPLIT && !QK8) ql[ks] = *(const V8*)(Ql + qo + 16 * ks);
+    }
+    if constexpr (QK8) {
+      const uint8_t* q8 = Q8 + ((size_t)bh * nq_pad + q) * 128 + 32 * h;
+      const u32x4 a0 = *(const u32x4*)q8, a1 = *(const u32x4*)(q8 + 16), b0 = *(const u32x4*)(q8 + 64), b1 = *(const u32x4*)(q8 + 80);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { q8h[e] = (int)a0[e]; q8h[4 + e] = (int)a1[e]; q8l[e] = (int)b0[e]; q8l[4 + e] = (int)b1[e]; }
     }
   }
 
@@ -119,7 +136,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 4 * i;
       GLDS16(kt + koff[i], sK + pc * 1024);
-      if constexpr (SPLIT) GLDS16((const char*)(kt + koff[i]) + kl_delta, sK + 2 * TILE + pc * 1024);
+      if constexpr (QK8)  // the 8-bit tile: 64 keys x (64 B e5m2(K) | 64 B e5m2(K_lo 2^10)) = the same 128-byte rows
+        GLDS16(K8 + ((size_t)bh * nk_pad + (size_t)t * 64) * 128 + koff[i] * 2, sK + 2 * TILE + pc * 1024);
+      else if constexpr (SPLIT) GLDS16((const char*)(kt + koff[i]) + kl_delta, sK + 2 * TILE + pc * 1024);
     }
   };
   auto stage_v = [&](int buf, int t) {
@@ -139,6 +158,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int k_base = perm23(r) * 128 + ((h ^ ((perm23(r) >> 1) & 7)) << 4);
   const int v_base = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
   auto k_addr = [&](int kb, int ks) { return kb * 4096 + (k_base ^ (ks << 5)); };
+  // 8-bit A operand of key row perm23(r): bytes 32 h .. 32 h + 31 of the e5m2(K) half (16-byte chunks 2h, 2h+1 of the
+  // row) or of the remainder half (chunks 4+2h, 5+2h), same XOR swizzle: one base, the chunk as an XOR immediate
+  const int k8_base = perm23(r) * 128 + (((2 * h) ^ ((perm23(r) >> 1) & 7)) << 4);
+  auto k8_read = [&](const char* sK, int kb, int lo) {
+    const char* p = sK + 2 * TILE + kb * 4096;
+    const u32x4 a0 = *(const u32x4*)(p + (k8_base ^ ((4 * lo) << 4))), a1 = *(const u32x4*)(p + (k8_base ^ ((4 * lo + 1) << 4)));
+    i32x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (int)a0[e]; v[4 + e] = (int)a1[e]; }
+    return v;
+  };
+  // cross terms of one 32-key block on the scaled 8-bit MFMA (e5m2 x e5m2; the remainder planes carry 2^10)
+  auto cross_hl = [&](const i32x8& k8, f32x16 c) {  // K8 (Q_lo8)^T
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k8, q8l, c, 1, 1, 0, 127, 0, VDN_LO8_E8M0);
+  };
+  auto cross_lh = [&](const i32x8& k8l, f32x16 c) {  // K_lo8 (Q8)^T
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k8l, q8h, c, 1, 1, 0, VDN_LO8_E8M0, 0, 127);
+  };
   auto v_addr = [&](int db, int c) { return db * 4096 + (v_base ^ (c << 5)); };
 
   f32x16 o[2];
@@ -157,11 +194,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ks = 0; ks < 4; ++ks) {
         const V8 a = *(const V8*)(sK + k_addr(kb, ks));
         sc[kb] = HT::mfma32(a, qf[ks], sc[kb]);
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && !QK8) {
           const V8 al = *(const V8*)(sK + 2 * TILE + k_addr(kb, ks));
           sc[kb] = HT::mfma32(a, ql[ks], sc[kb]);
           sc[kb] = HT::mfma32(al, qf[ks], sc[kb]);
         }
+      }
+      if constexpr (QK8) {
+        sc[kb] = cross_hl(k8_read(sK, kb, 0), sc[kb]);
+        sc[kb] = cross_lh(k8_read(sK, kb, 1), sc[kb]);
       }
     }
   };
@@ -224,6 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //   S[0] is last read in slot 20 and overwritten by QK(t+1) from slot 24, S[1] read in 36 (softmax piece
     //   first in the slot), overwritten from slot 36's MFMA on.
     V8 fa[2], fl[2];
+    i32x8 f8[2];  // QK8: the 8-bit K fragment of triples (kb, ks = 0) [e5m2(K)] and (kb, ks = 1) [remainder plane]
     auto frag = [&](auto jc, V8& a, V8& al) {
       constexpr int j = decltype(jc)::value;
       if constexpr (j < 8) {
@@ -233,7 +275,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       } else if constexpr (HAS_NEXT) {
         a = *(const V8*)(sKn + k_addr((j - 8) >> 2, (j - 8) & 3));
-        if constexpr (SPLIT) al = *(const V8*)(sKn + 2 * TILE + k_addr((j - 8) >> 2, (j - 8) & 3));
+        if constexpr (QK8) {
+          if constexpr (((j - 8) & 3) < 2) f8[j & 1] = k8_read(sKn, (j - 8) >> 2, (j - 8) & 3);
+        } else if constexpr (SPLIT) {
+          al = *(const V8*)(sKn + 2 * TILE + k_addr((j - 8) >> 2, (j - 8) & 3));
+        }
       }
     };
     auto mma = [&](auto jc, auto qc, const V8& a, const V8& al) {
@@ -253,6 +299,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int i = 0; i < 16; ++i) z[i] = 0.f;
           s[kb] = HT::mfma32(a, qf[ks], z);
+        } else if constexpr (QK8) {
+          // 6 MFMAs per 32-key block in its 12 slots: 4 fp16 (q == 0) + the two 8-bit cross terms in the q == 1 slots
+          // of ks = 0, 1 (twice as long as a fp16 MFMA: they hide two softmax pieces); the other slots are VALU-only
+          if constexpr (q == 0) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
+          if constexpr (q == 1 && ks == 0) s[kb] = cross_hl(f8[j & 1], s[kb]);
+          if constexpr (q == 1 && ks == 1) s[kb] = cross_lh(f8[j & 1], s[kb]);
         } else {
           if constexpr (q == 0) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
           if constexpr (q == 1) s[kb] = HT::mfma32(a, ql[ks], s[kb]);
@@ -600,19 +652,25 @@ int& pv_products() {
 
 template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
-                 void* outl, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
+                 void* outl, const void* Q8, const void* K8, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
   using T = typename Half<DT>::T;
   const dim3 grid(((nq + 127) / 128) * B * H);
   const bool pv3 = pv_products() == 3;  // the 3-product P V with P split into hi / lo planes (vdn_flash_attn_set_pv_products)
+  const uint8_t* q8 = (const uint8_t*)Q8;
+  const uint8_t* k8 = (const uint8_t*)K8;
   if (Ql && pv3)
-    hipLaunchKernelGGL((flash_attn_kernel<DT, true, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
-  else if (Ql)
-    hipLaunchKernelGGL((flash_attn_kernel<DT, true, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, H, nq, nq_pad, nk, nk_pad, sl2);
+    hipLaunchKernelGGL((flash_attn_kernel<DT, true, false, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+  else if (Ql && q8 && k8 && DT == VDN_F16) {
+    if constexpr (DT == VDN_F16)
+      hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                         (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+  } else if (Ql)
+    hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                       (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
   else
-    hipLaunchKernelGGL((flash_attn_kernel<DT, false, false>), grid, dim3(256), 32768, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                       (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)outl, H, nq, nq_pad, nk,
+    hipLaunchKernelGGL((flash_attn_kernel<DT, false, false, false>), grid, dim3(256), 32768, s, (const T*)Q, (const T*)K, (const T*)Vt,
+                       (T*)out, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (T*)outl, q8, k8, H, nq, nq_pad, nk,
                        nk_pad, sl2);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
@@ -646,21 +704,22 @@ extern "C" int vdn_flash_attn_set_pv_products(int n) {
 extern "C" int vdn_flash_attn_get_pv_products(void) { return pv_products(); }
 
 extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
-                              const void* K_lo, const void* Vt_lo, void* out_lo, int B, int H, int nq, int nq_pad, int nk,
-                              int nk_pad, float scale, vdn_stream stream) {
+                              const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, int B, int H,
+                              int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream) {
   if (!Q || !K || !Vt || !out || B <= 0 || H <= 0 || nq <= 0 || nk <= 0) return VDN_EINVAL;
   if (nq_pad < nq || nk_pad < nk || (nk_pad & 63)) return VDN_EALIGN;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)out) & 15) return VDN_EALIGN;
   const int nlo = (Q_lo != nullptr) + (K_lo != nullptr) + (Vt_lo != nullptr);
   if (nlo != 0 && nlo != 3) return VDN_EINVAL;  // operand planes are all-or-nothing; the output may be split either way
   if (nlo == 3 && !out_lo) return VDN_EINVAL;
-  if (((uintptr_t)Q_lo | (uintptr_t)K_lo | (uintptr_t)Vt_lo | (uintptr_t)out_lo) & 15) return VDN_EALIGN;
+  if (((uintptr_t)Q_lo | (uintptr_t)K_lo | (uintptr_t)Vt_lo | (uintptr_t)out_lo | (uintptr_t)Q8 | (uintptr_t)K8) & 15) return VDN_EALIGN;
+  if ((Q8 == nullptr) != (K8 == nullptr) || (Q8 && (nlo != 3 || dt != VDN_F16))) return VDN_EINVAL;  // 8-bit planes come in pairs, split fp16 only
   const float sl2 = scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;
   if (dt == VDN_F16)
-    return flash_launch<VDN_F16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
+    return flash_launch<VDN_F16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, Q8, K8, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
   if (dt == VDN_BF16)
-    return flash_launch<VDN_BF16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
+    return flash_launch<VDN_BF16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, nullptr, nullptr, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
   return VDN_EUNSUPPORTED;
 }
 

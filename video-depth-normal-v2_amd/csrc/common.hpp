@@ -194,6 +194,17 @@ __device__ __forceinline__ void split2_rtz(float x0, float x1, __bf16& h0, __bf1
   split_rtz(x0, h0, l0);
   split_rtz(x1, h1, l1);
 }
+// 8-bit planes of a split value for the attention cross terms (include/vdn.h: vdn_gemm_desc.dst8): e5m2 of the value
+// and e5m2 of its fp16 remainder scaled by 2^10 (e5m2 shares fp16's exponent range, so neither needs a block scale;
+// the attention kernel undoes the 2^10 with the MFMA's E8M0 scale operand).
+__device__ __forceinline__ uint32_t pk4_bf8(float a, float b, float c, float d) {
+  int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+  return (uint32_t)v;
+}
+constexpr float VDN_LO8_SCALE = 1024.0f;  // 2^10; E8M0 byte 127 - 10 on the other side
+constexpr int VDN_LO8_E8M0 = 117;
+
 // store 1 value: hi-only (round to nearest) or split planes
 template <typename T>
 __device__ __forceinline__ void store_half(T* hi, T* lo, size_t i, float v) {

@@ -180,6 +180,12 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
       *(typename H::V4*)(dst + o) = h;
       *(typename H::V4*)(dlo + o) = l;
+      if (p.dst8[split]) {
+        uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + e0;
+        const float k = VDN_LO8_SCALE;
+        *(uint32_t*)d8 = pk4_bf8(a[0], a[1], a[2], a[3]);
+        *(uint32_t*)(d8 + 64) = pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]);
+      }
     }
     return;
   }
@@ -279,6 +285,13 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
         }
         *(typename H::V8*)(dst + o) = h8;
         if (dlo) *(typename H::V8*)(dlo + o) = l8;
+        if (dlo && p.dst8[split]) {
+          uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + 2 * pi;
+          const float k = VDN_LO8_SCALE;
+          *(u32x2*)d8 = u32x2{pk4_bf8(o8[0], o8[1], o8[2], o8[3]), pk4_bf8(o8[4], o8[5], o8[6], o8[7])};
+          *(u32x2*)(d8 + 64) = u32x2{pk4_bf8(k * (float)l8[0], k * (float)l8[1], k * (float)l8[2], k * (float)l8[3]),
+                                     pk4_bf8(k * (float)l8[4], k * (float)l8[5], k * (float)l8[6], k * (float)l8[7])};
+        }
       }
       return;
     }
@@ -295,6 +308,12 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
       }
       *(typename H::V4*)(dst + o) = h;
       if (dlo) *(typename H::V4*)(dlo + o) = l;
+      if (dlo && p.dst8[split]) {
+        uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + e0;
+        const float k = VDN_LO8_SCALE;
+        *(uint32_t*)d8 = pk4_bf8(a[0], a[1], a[2], a[3]);
+        *(uint32_t*)(d8 + 64) = pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]);
+      }
     }
   }
 }
@@ -368,6 +387,13 @@ __device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
       *(V8*)(dst + o) = h;
       *(V8*)(dlo + o) = l;
+      if (p.dst8[split]) {  // e5m2 planes for the attention cross terms
+        uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + e0;
+        *(u32x2*)d8 = u32x2{pk4_bf8(a[0], a[1], a[2], a[3]), pk4_bf8(a[4], a[5], a[6], a[7])};
+        const float k = VDN_LO8_SCALE;
+        *(u32x2*)(d8 + 64) = u32x2{pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]),
+                                   pk4_bf8(k * (float)l[4], k * (float)l[5], k * (float)l[6], k * (float)l[7])};
+      }
     }
   } else {
     const size_t o = (size_t)m * p.ldc + n;

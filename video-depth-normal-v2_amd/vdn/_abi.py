@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("A_lo", vp), ("W_lo", vp), ("out_lo", vp), ("dst_lo", vp * 3), ("res1_lo", vp), ("res2_lo", vp),
         ("conv_korder", i32), ("cu_hint", i32),
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("ksplit", i32),
+        ("dst8", vp * 3),
     ]
 
 
@@ -69,7 +70,7 @@ EXPORTS = {
     "vdn_gemm_set_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
     "vdn_layernorm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_float, fp, C.c_int, C.c_int,
                                 C.c_int, vp, vp, C.c_int, fp, vp]),
-    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_float, vp]),
     "vdn_flash_attn_set_pv_products": (C.c_int, [C.c_int]),
     "vdn_flash_attn_get_pv_products": (C.c_int, []),

@@ -86,15 +86,16 @@ class EncoderEngine:
         q = rt.hbuf("enc_q", (Bf * Hh, npad, 64), zero=True)
         k = rt.hbuf("enc_k", (Bf * Hh, npad, 64), zero=True)
         vt = rt.hbuf("enc_vt", (Bf * Hh, 64, npad), zero=True)
+        q8, k8 = rt.qk8("enc_q8", Bf * Hh, npad), rt.qk8("enc_k8", Bf * Hh, npad)  # e5m2 planes for the score cross terms
         hn = rt.hbuf("enc_ln", (M, C))
         att = rt.hbuf("enc_att", (M, C))
         f1 = rt.hbuf("enc_fc1", (M, 4 * C))
-        heads = dict(dst=[q, k, vt], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
+        heads = dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
         outs, last_f32 = [], None
         for i, b in enumerate(self.blocks):
             rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
             rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear")
-            rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn")
+            rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn", q8=q8, k8=k8)
             rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear")
             rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
             rt.gemm(hn, b["wfc1"], M, 4 * C, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
@@ -456,14 +457,16 @@ class MemoryEngine:
         tp = ceil_to(self.max_len * P, 64)
         ks = [rt.hbuf(f"mem_k{l}", (B * Hh, tp, 64), zero=True) for l in range(len(self.layers))]
         vs = [rt.hbuf(f"mem_vt{l}", (B * Hh, 64, tp), zero=True) for l in range(len(self.layers))]
-        return ks, vs, tp
+        k8 = [rt.qk8(f"mem_k8{l}", B * Hh, tp) for l in range(len(self.layers))]  # e5m2 planes of the stored keys
+        return ks, vs, k8, tp
 
     def _bank(self, B, P):
         """This lane's rows of the ring: B is the lane's batch."""
         i, n = self.lane
-        ks, vs, tp = self._bank_full(B * n, P)
+        ks, vs, k8, tp = self._bank_full(B * n, P)
         r0, nr = i * B * self.heads, B * self.heads
-        return [k.narrow0(r0, nr) for k in ks], [v.narrow0(r0, nr) for v in vs], tp
+        return ([k.narrow0(r0, nr) for k in ks], [v.narrow0(r0, nr) for v in vs],
+                [None if t is None else t.narrow(0, r0, nr) for t in k8], tp)
 
     def forward(self, feat_f32: torch.Tensor, B: int, P: int) -> torch.Tensor:
         """feat_f32 [B*P, C] (final-normed tap 4) -> half [B*P, C] (memory_block.py:92-125)."""
@@ -479,9 +482,10 @@ class MemoryEngine:
         q = rt.hbuf("ma_q", (B * Hh, pp, 64), zero=True)
         k = rt.hbuf("ma_k", (B * Hh, pp, 64), zero=True)
         vt = rt.hbuf("ma_vt", (B * Hh, 64, pp), zero=True)
+        q8, k8 = rt.qk8("ma_q8", B * Hh, pp), rt.qk8("ma_k8", B * Hh, pp)
         att = rt.hbuf("ma_att", (M, C))
         h2 = rt.hbuf("ma_h2", (M, 2 * C))
-        ks, vs, tp = self._bank(B, P)
+        ks, vs, k8s, tp = self._bank(B, P)
         S = self.S
         if S == 0:
             # empty bank: keys/values come from no_mem_embed broadcast to P tokens (memory_block.py:115-123)
@@ -491,22 +495,24 @@ class MemoryEngine:
             a_nm = self._nomem[M]
             ks = [rt.hbuf(f"nomem_k{l}", (B * Hh, pp, 64), zero=True) for l in range(len(self.layers))]
             vs = [rt.hbuf(f"nomem_vt{l}", (B * Hh, 64, pp), zero=True) for l in range(len(self.layers))]
+            k8s = [rt.qk8(f"nomem_k8{l}", B * Hh, pp) for l in range(len(self.layers))]
             for l, L in enumerate(self.layers):
                 rt.gemm(a_nm, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
-                        heads=dict(dst=[ks[l], vs[l]], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
-                                   tokens=P, tpad=pp))
+                        heads=dict(dst=[ks[l], vs[l]], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs,
+                                   rope_mod=P, heads=Hh, tokens=P, tpad=pp))
         else:
             nk, nk_pad = S * P, tp
-        sh = dict(dst=[q, k, vt], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
-        qh = dict(dst=[q], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
+        sh = dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
+                  tokens=P, tpad=pp)
+        qh = dict(dst=[q], dst8=[q8], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
         for l, L in enumerate(self.layers):
             rt.layernorm(x, M, C, L["n1w"], L["n1b"], 1e-5, out_h=n)
             rt.gemm(n, L["wqkv"], M, 3 * C, C, bias=L["bqkv"], store=abi.ST_HEADS, heads=sh)
-            rt.flash_attn(q, k, vt, att, B, Hh, P, pp, P, pp, 0.125)
+            rt.flash_attn(q, k, vt, att, B, Hh, P, pp, P, pp, 0.125, q8=q8, k8=k8)
             rt.gemm(att, L["wso"], M, C, C, bias=L["bso"], res1=x, out=x)
             rt.layernorm(x, M, C, L["n2w"], L["n2b"], 1e-5, out_h=n, addvec=self.curr_pos, alpha=1.0)
             rt.gemm(n, L["wq"], M, C, C, bias=L["bq"], store=abi.ST_HEADS, heads=qh)
-            rt.flash_attn(q, ks[l], vs[l], att, B, Hh, P, pp, nk, nk_pad, 0.125)
+            rt.flash_attn(q, ks[l], vs[l], att, B, Hh, P, pp, nk, nk_pad, 0.125, q8=q8, k8=k8s[l])
             rt.gemm(att, L["wco"], M, C, C, bias=L["bco"], res1=x, out=x)
             rt.layernorm(x, M, C, L["n3w"], L["n3b"], 1e-5, out_h=n)
             rt.gemm(n, L["w1"], M, 2 * C, C, bias=L["b1"], act=GELU, out=h2)
@@ -539,11 +545,11 @@ class MemoryEngine:
             rt.layernorm(d, M, C, cx["nw"], cx["nb"], 1e-6, out_h=n)
             rt.gemm(n, cx["w1"], M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4)
             rt.gemm(h4, cx["w2"], M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=(x if j == 0 else feat))
-        ks, vs, tp = self._bank(B, P)
+        ks, vs, k8s, tp = self._bank(B, P)
         slot = self.state["count"] % self.max_len  # commit() advances the count once every lane has pushed
         cs = self._rope_for(int(math.sqrt(P)))
         for l, L in enumerate(self.layers):
             rt.gemm(feat, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
-                    heads=dict(dst=[ks[l], vs[l]], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
-                               tokens=P, tok_off=slot * P, tpad=tp))
+                    heads=dict(dst=[ks[l], vs[l]], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P,
+                               heads=Hh, tokens=P, tok_off=slot * P, tpad=tp))
         return feat

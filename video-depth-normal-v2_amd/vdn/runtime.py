@@ -103,6 +103,13 @@ class Runtime:
     def to_half(self, x: torch.Tensor) -> HL:
         return HL.from_float(x, self.half, self.split)
 
+    def qk8(self, name: str, bh: int, tpad: int) -> Optional[torch.Tensor]:
+        """u8 [bh, tpad, 128] zero-initialised plane pair for the attention's 8-bit cross terms, or None when the
+        mode has none (single-product or bf16 planes, or VDN_ATTN_QK8=0)."""
+        if not (self.split and self.half == torch.float16) or os.environ.get("VDN_ATTN_QK8", "1") == "0":
+            return None
+        return self.buf(name, (bh, tpad, 128), torch.uint8, zero=True)
+
     def fbuf(self, name, shape, zero=False):
         return self.buf(name, shape, torch.float32, zero)
 
@@ -179,6 +186,9 @@ class Runtime:
                 d.dst[i] = th.data_ptr()
                 d.transposed[i] = int(heads["transposed"][i])
                 d.rope[i] = int(heads.get("rope", (0, 0, 0))[i])
+                t8 = (heads.get("dst8") or (None, None, None))[i]
+                if t8 is not None:
+                    d.dst8[i] = t8.data_ptr()
             d.heads, d.tokens, d.tok_off, d.tpad = heads["heads"], heads["tokens"], heads.get("tok_off", 0), heads["tpad"]
             if heads.get("rope_cs") is not None:
                 d.rope_cs, d.rope_mod = heads["rope_cs"].data_ptr(), heads["rope_mod"]
@@ -201,10 +211,12 @@ class Runtime:
                      self._p(out_f))
 
     def flash_attn(self, Q, K, Vt, out, B: int, H: int, nq: int, nq_pad: int, nk: int, nk_pad: int, scale: float,
-                   tag: Optional[str] = None):
+                   tag: Optional[str] = None, q8: Optional[torch.Tensor] = None, k8: Optional[torch.Tensor] = None):
+        """q8 / k8: the u8 [B*H, n_pad, 128] planes the projection wrote through heads['dst8'] (8-bit cross terms)."""
         (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
         self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
-                     vl, ol, B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag, flop=4.0 * B * H * nq * nk * 64)
+                     vl, ol, self._p(q8), self._p(k8), B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag,
+                     flop=4.0 * B * H * nq * nk * 64)
 
     def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
         (qkv, ql), (out, ol) = _hl(qkv), _hl(out)
