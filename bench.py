@@ -139,6 +139,23 @@ class _StubVideoModel:
         y = shard_core(ex, planes, H * W, lambda pl, D: [self._mix(pl[0].reshape(ex.T, D, c)).reshape(ex.T * D, c)])[0]
         return y.reshape(Tl, H * W, c).mean(-1).abs().reshape(1, Tl, H, W) + 0.25
 
+    # staged interface (vdn/dist.py: encode distinct frames once, exchange taps, run heads): same numbers as forward()
+    def encode_frames(self, x):
+        k, c, H, W = x.shape
+        return [x.permute(0, 2, 3, 1).reshape(k * H * W, c).contiguous()], H * W, (H, W)
+
+    def head_from_planes(self, planes, Tl, T, hw, group=None):
+        from vdn.dist import FrameShardExchange, shard_core
+        H, W = hw
+        c = planes[0].shape[-1]
+        if group is None:
+            y = self._mix(planes[0].reshape(T, H * W, c))
+        else:
+            ex = FrameShardExchange(T, group)
+            y = shard_core(ex, [planes[0].contiguous()], H * W,
+                           lambda pl, D: [self._mix(pl[0].reshape(ex.T, D, c)).reshape(ex.T * D, c)])[0].reshape(Tl, H * W, c)
+        return y.mean(-1).abs().reshape(Tl, H, W) + 0.25
+
     def infer_video_depth(self, frames, fps, input_size=518):
         from vdn.dist import infer_video_depth_sharded
         return infer_video_depth_sharded(self, frames, fps, input_size=input_size)

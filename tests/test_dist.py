@@ -84,9 +84,11 @@ def _worker_hybrid(rank, world, port, out, n):
     m = bench._StubVideoModel()
     d, fps = infer_video_depth_sharded(m, frames, 30, input_size=28, all_ranks=True)
     d0, _ = infer_video_depth_sharded(m, frames, 30, input_size=28, all_ranks=False)
+    # the same clip through the per-job path (whole forward / forward_sharded per window, no tap exchange)
+    d1, _ = infer_video_depth_sharded(m, frames, 30, input_size=28, forward=m.forward, forward_sharded=m.forward_sharded)
     ref = _reference_clip(frames)
     ok = d.shape == (n, 28, 42) and np.allclose(d, ref, rtol=1e-5, atol=1e-6) and fps == 30
-    ok = ok and ((d0 is None) if rank else np.array_equal(d0, d))
+    ok = ok and ((d0 is None) if rank else np.array_equal(d0, d)) and np.allclose(d1, d, rtol=1e-6, atol=1e-7)
     jobs = plan_schedule(len(__import__("vdn.util", fromlist=["x"]).window_table(n)), world)
     out[rank] = (bool(ok), jobs)
     dist.destroy_process_group()
@@ -131,6 +133,17 @@ def test_schedule_and_payload():
             jobs = plan_schedule(nw, P)
             assert sorted(j[0] for j in jobs) == list(range(nw))
             assert all(0 <= j[1] and j[1] + j[2] <= P and 32 % j[2] == 0 for j in jobs)
+    # BASELINE configs[3]: the 256 distinct frames of the clip are encoded once, 32 per rank (not 48 = 1.5 windows);
+    # every rank's heads read 48 frames' taps, of which at most 32 are its own
+    from vdn import util
+    from vdn.dist import tap_exchange_plan
+    table = util.window_table(256)
+    frames, per, local, need, send = tap_exchange_plan(table, plan_schedule(len(table), 8), 8)
+    assert len(frames) == 256 and per == 32 and all(len(l) == 32 for l in local)
+    assert sorted(len(x) for x in need) == [47, 47, 47, 47, 48, 48, 48, 48] or max(len(x) for x in need) <= 48
+    for dst in range(8):
+        got = sorted(f for src in range(8) for f in send[src][dst])
+        assert got == need[dst] and all(f in local[src] for src in range(8) for f in send[src][dst])
     ex = FrameShardExchange(32)      # world size 1: identity exchange
     x = torch.randn(32, 10, 4)
     assert ex.frames_to_pixels(x) is x and ex.pixels_to_frames(x, 10) is x

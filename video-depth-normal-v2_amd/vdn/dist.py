@@ -8,8 +8,12 @@ Both levels are new design (the reference has no multi-GPU inference):
   given the input frames (vdn.util.window_table). Full rounds deal one window to every rank; the windows
   left over for the last, partial round are each FRAME-SHARDED over a group of ranks, so no rank idles:
   12 windows on 8 GPUs = 8 whole windows + 4 windows on 2 GPUs each = 1.5 window-times instead of 2
-  (ideal strong-scaling efficiency 1.0 instead of 0.75). The per-window depth maps are gathered to rank 0
-  once per clip for the (cheap, sequential) stitcher.
+  (ideal strong-scaling efficiency 1.0 instead of 0.75). The ENCODER does not follow the windows at all: it is
+  per-frame, and 10 of every window's 32 slots repeat earlier input frames, so the clip's distinct frames are split
+  evenly over the ranks, each is encoded once, and the ranks exchange the taps their heads read
+  (`tap_exchange_plan`, `exchange_taps`: the all-gather of per-frame feature memory of the north star, sent only to
+  the ranks that need each frame). The per-window depth maps are gathered to rank 0 once per clip for the (cheap,
+  sequential) stitcher.
 
 * frames inside a window — `FrameShardExchange`, `shard_core`: the encoder and every convolution are
   per-frame, only the 4 temporal modules mix frames, and they do so independently per pixel. Each rank keeps
@@ -87,14 +91,86 @@ def _subgroups(nranks: int, g: int):
 
 
 # --------------------------------------------------------------------------------------------- driver
+def tap_exchange_plan(table, jobs, nranks: int, T: int = util.INFER_LEN):
+    """Who encodes which frame and who needs which frame's encoder taps (a pure function of the window table and
+    the schedule, identical on every rank). Distinct frames are split into contiguous blocks, one per rank (the
+    encoder is per-frame, so this is perfectly balanced: 256 frames / 8 ranks = 32 each, not 48 = 1.5 windows);
+    rank r then needs the frames of its head jobs. Returns (frames, per, local[r], need[r], send[src][dst])."""
+    frames = sorted({f for row in table for f in row})
+    per = (len(frames) + nranks - 1) // nranks
+    pos = {f: i for i, f in enumerate(frames)}
+    local = [frames[r * per:(r + 1) * per] for r in range(nranks)]
+    need = [[] for _ in range(nranks)]
+    for (w, r0, g) in jobs:
+        Tl = T // g
+        for k in range(g):
+            need[r0 + k] += table[w][k * Tl:(k + 1) * Tl]
+    need = [sorted(set(n)) for n in need]
+    send = [[[f for f in need[dst] if pos[f] // per == src] for dst in range(nranks)] for src in range(nranks)]
+    return frames, per, local, need, send
+
+
+def exchange_taps(planes: List[torch.Tensor], rows_per_frame: int, local: List[int], send, r: int, group=None):
+    """One all-to-all (variable splits) per plane: every rank hands each peer the tap rows of the frames that peer's
+    head jobs read (`send[r][dst]`) — the RCCL exchange of per-frame feature memory over xGMI. Returns
+    (received planes, {frame: first row}). planes: [len(local) * rows_per_frame, C] tensors of this rank's frames."""
+    P = len(send)
+    lpos = {f: i for i, f in enumerate(local)}
+    idx_out = [f for dst in range(P) for f in send[r][dst]]
+    in_split = [len(send[r][dst]) * rows_per_frame for dst in range(P)]
+    out_split = [len(send[src][r]) * rows_per_frame for src in range(P)]
+    where, row = {}, 0
+    for src in range(P):
+        for f in send[src][r]:
+            where[f] = row
+            row += rows_per_frame
+    got = []
+    for pl in planes:
+        C = pl.shape[-1]
+        sbuf = pl.new_empty((sum(in_split), C))
+        for i, f in enumerate(idx_out):
+            sbuf[i * rows_per_frame:(i + 1) * rows_per_frame].copy_(pl[lpos[f] * rows_per_frame:(lpos[f] + 1) * rows_per_frame])
+        rbuf = pl.new_empty((sum(out_split), C))
+        if P > 1:
+            dist.all_to_all_single(rbuf, sbuf, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        else:
+            rbuf.copy_(sbuf)
+        got.append(rbuf)
+    return got, where
+
+
+def _slot_rows(planes: List[torch.Tensor], where, slots: Sequence[int], rows_per_frame: int) -> List[torch.Tensor]:
+    """Rows of `slots` (frame ids, repeats allowed) as [len(slots) * rows_per_frame, C] tensors: in place when the
+    slots are one ascending run of the received rows, else copied run by run."""
+    starts = [where[f] for f in slots]
+    n = rows_per_frame
+    if all(starts[i + 1] == starts[i] + n for i in range(len(starts) - 1)):
+        return [pl[starts[0]:starts[0] + len(slots) * n] for pl in planes]
+    out = [pl.new_empty((len(slots) * n, pl.shape[-1])) for pl in planes]
+    i = 0
+    while i < len(slots):
+        k = i
+        while k + 1 < len(slots) and starts[k + 1] == starts[k] + n:
+            k += 1
+        for src, dst in zip(planes, out):
+            dst[i * n:(k + 1) * n].copy_(src[starts[i]:starts[k] + n])
+        i = k + 1
+    return out
+
+
 def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size: int = 518, group=None,
                               forward: Optional[Callable] = None, forward_sharded: Optional[Callable] = None,
                               all_ranks: bool = True):
     """Multi-GPU twin of VideoDepthAnything.infer_video_depth (video_depth.py:67-156) over the default process
     group. Returns (f32 [N,h,w], target_fps) on rank 0 — and on every rank when `all_ranks` (one broadcast of
     the stitched clip) — else (None, target_fps).
-    `forward(window [1,32,3,H,W]) -> [1,32,H,W]` and `forward_sharded(local frames [1,32/g,3,H,W], group) ->
-    [1,32/g,H,W]` default to the model's methods (tests inject stubs)."""
+
+    A model with `encode_frames` / `head_from_planes` (the product, and bench.py's stand-in) runs in three phases:
+    every rank ENCODES its contiguous share of the clip's distinct frames (no frame is encoded twice, on any rank),
+    the ranks EXCHANGE the encoder taps their head jobs read (`exchange_taps`: one variable-split all-to-all per
+    plane), then the HEADS run per the schedule: whole windows, and the last partial round's windows frame-sharded
+    over groups of ranks. Otherwise `forward(window [1,32,3,H,W]) -> [1,32,H,W]` / `forward_sharded(local frames
+    [1,32/g,3,H,W], group) -> [1,32/g,H,W]` are called per job (tests inject stubs)."""
     assert group is None, "the schedule builds its own subgroups of the default group"
     P, r = world(), rank()
     fh, fw = frames[0].shape[:2]
@@ -120,19 +196,34 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
         need = sorted(set(idxs))
         pos = {f: i for i, f in enumerate(need)}
         net = prep(frames[need], input_size) if prep else torch.from_numpy(frames[need]).float()
-        return net[[pos[f] for f in idxs]][None]
+        return net[[pos[f] for f in idxs]]
 
     pieces: List[torch.Tensor] = []   # this rank's depth frames in job order
-    for (w, r0, g) in jobs:
-        if not (r0 <= r < r0 + g):
-            continue
-        if g == 1:
-            d = fwd(net_input(table[w]))[0]
-        else:
-            Tl = T // g
-            k = r - r0
-            d = fwd_sh(net_input(table[w][k * Tl:(k + 1) * Tl]), groups[g][r0 // g])[0]
-        pieces.append((resize(d, fh, fw) if resize else d).float())
+    staged = forward is None and forward_sharded is None and hasattr(model, "encode_frames")
+    if staged:
+        _, _, local, _, send = tap_exchange_plan(table, jobs, P, T)
+        mine = local[r]
+        x_mine = net_input(mine) if mine else net_input(table[0][:1])[:0]  # a rank may own no frame (tiny clips)
+        planes, rpf, hw = model.encode_frames(x_mine)   # rows per frame, (H, W) of the network input
+        got, where = exchange_taps(planes, rpf, mine, send, r)
+        for (w, r0, g) in jobs:
+            if not (r0 <= r < r0 + g):
+                continue
+            Tl, k = T // g, r - r0
+            slots = table[w][k * Tl:(k + 1) * Tl]
+            d = model.head_from_planes(_slot_rows(got, where, slots, rpf), Tl, T, hw, None if g == 1 else groups[g][r0 // g])
+            pieces.append((resize(d, fh, fw) if resize else d).float().clone())
+    else:
+        for (w, r0, g) in jobs:
+            if not (r0 <= r < r0 + g):
+                continue
+            if g == 1:
+                d = fwd(net_input(table[w])[None])[0]
+            else:
+                Tl = T // g
+                k = r - r0
+                d = fwd_sh(net_input(table[w][k * Tl:(k + 1) * Tl])[None], groups[g][r0 // g])[0]
+            pieces.append((resize(d, fh, fw) if resize else d).float())
 
     # ---- gather every rank's frames to rank 0 (equal slabs; the schedule tells who holds what)
     counts = [0] * P

@@ -66,9 +66,10 @@ class EncoderEngine:
             self._pos_cache[key] = (table, (self.cls + table[0]).contiguous())
         return self._pos_cache[key]
 
-    def run(self, x: torch.Tensor, want_f32_last: bool = False):
+    def run(self, x: torch.Tensor, want_f32_last: bool = False, tap_out=None):
         """x f32 [Bf,3,H,W] -> 4 final-normed patch-token maps, half [Bf*P, C] each (cls dropped,
-        dinov2.py:309-312); optionally also the last one in f32 (input of the memory block)."""
+        dinov2.py:309-312); optionally also the last one in f32 (input of the memory block).
+        `tap_out`: 4 caller-owned HL destinations [Bf*P, C] (the clip-level tap cache of the video driver)."""
         rt, C, Hh = self.rt, self.C, self.heads
         Bf, _, H, W = x.shape
         assert H % PATCH == 0 and W % PATCH == 0, "input sides must be multiples of 14 (patch_embed.py:73-74)"
@@ -102,7 +103,7 @@ class EncoderEngine:
             rt.gemm(f1, b["wfc2"], M, C, 4 * C, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
             if i in self.taps:
                 j = self.taps.index(i)
-                t = rt.hbuf(f"tap{j}", (Bf * P, C))
+                t = tap_out[j] if tap_out is not None else rt.hbuf(f"tap{j}", (Bf * P, C))
                 f = None
                 if want_f32_last and j == len(self.taps) - 1:
                     f = last_f32 = rt.fbuf("tap_last_f32", (Bf * P, C))

@@ -108,6 +108,44 @@ class VideoDepthAnything(_EngineOwner):
         depth = head.run(taps, Tl, ph, pw, T=exch.T, relu=not _pre_relu, exch=exch)
         return depth.reshape(1, Tl, H, W).clone()
 
+    # ------------------------------------------------------------------ staged interface of the multi-GPU driver (vdn/dist.py)
+    @torch.no_grad()
+    def encode_frames(self, x: torch.Tensor):
+        """x [k,3,H,W] (k >= 0) -> (planes, rows_per_frame, (H, W)): the 4 final-normed encoder taps of the k frames as
+        plain 2-D tensors [k*P, C] (hi and lo planes of tap 0, then tap 1, ...), which is what vdn.dist exchanges."""
+        e = self._engines()
+        rt, enc = e["rt"], e["enc"]
+        k, _, H, W = x.shape
+        P, C = (H // 14) * (W // 14), self.pretrained.embed_dim
+        out = [rt.hbuf(f"enc_share_tap{j}", (max(k, 1) * P, C)) for j in range(4)]
+        xf = x.to(device=rt.device, dtype=torch.float32)
+        for c0 in range(0, k, util.INFER_LEN):
+            c1 = min(k, c0 + util.INFER_LEN)
+            enc.run(xf[c0:c1].contiguous(), tap_out=[t.narrow0(c0 * P, (c1 - c0) * P) for t in out])
+        planes = []
+        for t in out:
+            planes.append(t.hi[:k * P])
+            if t.lo is not None:
+                planes.append(t.lo[:k * P])
+        return planes, P, (H, W)
+
+    @torch.no_grad()
+    def head_from_planes(self, planes, Tl: int, T: int, hw, group=None) -> torch.Tensor:
+        """The temporal DPT head on the taps of Tl frames (planes as returned by encode_frames, rows of these Tl frames in
+        slot order) -> depth [Tl,H,W]. group None: a whole window (Tl == T); else this rank's Tl of the T frames of a
+        window that is frame-sharded over `group` (all-to-all around each temporal module)."""
+        from .dist import FrameShardExchange
+        from .runtime import HL
+        e = self._engines()
+        rt, head = e["rt"], e["head"]
+        H, W = hw
+        per = 2 if rt.split else 1
+        taps = [HL(planes[per * j], planes[per * j + 1] if rt.split else None) for j in range(4)]
+        exch = None if group is None else FrameShardExchange(T, group)
+        assert exch is not None or Tl == T
+        depth = head.run(taps, Tl, H // 14, W // 14, T=T, exch=exch)
+        return depth.reshape(Tl, H, W)
+
     def preprocess_frames(self, frames: np.ndarray, input_size: int) -> torch.Tensor:
         """u8 RGB [n,h,w,3] -> normalised f32 [n,3,H,W] on the device (video_depth.py:73-99)."""
         rt = self._engines()["rt"]
@@ -137,11 +175,62 @@ class VideoDepthAnything(_EngineOwner):
             input_size = round(input_size / 14) * 14
         n = frames.shape[0]
         net_in = self.preprocess_frames(frames, input_size)  # [n,3,H,W]
-        st = DeviceStitcher(rt, len(util.window_table(n)), fh, fw)
-        for idxs in util.window_table(n):
-            cur = net_in[torch.tensor(idxs, device=rt.device)][None]
-            st.push(self.resize_depth(self.forward(cur)[0], fh, fw))  # [32,fh,fw], stays on the device
+        table = util.window_table(n)
+        st = DeviceStitcher(rt, len(table), fh, fw)
+        for d in self.window_depths(net_in, table):
+            st.push(self.resize_depth(d, fh, fw))  # [32,fh,fw], stays on the device
         return st.result(n).cpu().numpy(), target_fps  # the clip's only device-to-host copy
+
+    # bytes of encoder taps one frame keeps in the clip-level cache: 4 taps x P tokens x C channels x 16-bit planes
+    def _tap_bytes_per_frame(self, H: int, W: int) -> int:
+        rt = self._engines()["rt"]
+        return 4 * (H // 14) * (W // 14) * self.pretrained.embed_dim * 2 * (2 if rt.split else 1)
+
+    def window_depths(self, net_in: torch.Tensor, table, windows=None):
+        """Depth [32,H,W] of the windows `windows` (default: all) of a clip whose pre-processed frames are net_in [n,3,H,W].
+        The reference runs the encoder on all 32 slots of every window (video_depth.py:96-103), but 10 of the 32 are
+        copies of earlier input frames (Appendix B of SURVEY.md: slot 0 = frame 0, slot 1 = the previous window's
+        keyframe, slots 2..9 = the previous window's last 8), and the encoder is per-frame: here every DISTINCT frame
+        goes through the encoder once (its 4 final-normed taps stay in HBM, 22 MB per 518x518 ViT-L frame), and a
+        window's head reads its 32 slots from that cache — 256 instead of 384 encoder passes for a 256-frame clip,
+        same numbers. Falls back to per-window encoding when the cache would not fit (VDN_TAP_CACHE_GB, default 96)."""
+        import os
+        e = self._engines()
+        rt, enc, head = e["rt"], e["enc"], e["head"]
+        n, _, H, W = net_in.shape
+        windows = list(range(len(table))) if windows is None else list(windows)
+        need = sorted({f for w in windows for f in table[w]})
+        budget = float(os.environ.get("VDN_TAP_CACHE_GB", "96")) * 2 ** 30
+        if len(need) * self._tap_bytes_per_frame(H, W) > budget:
+            for w in windows:
+                yield self.forward(net_in[torch.tensor(table[w], device=rt.device)][None])[0]
+            return
+        ph, pw = H // 14, W // 14
+        P, C = ph * pw, self.pretrained.embed_dim
+        slot = {f: i for i, f in enumerate(need)}        # cache row block of frame f
+        cache = [rt.hbuf(f"clip_tap{j}", (len(need) * P, C)) for j in range(4)]
+        for c0 in range(0, len(need), util.INFER_LEN):   # encoder batches of 32 distinct frames
+            fr = need[c0:c0 + util.INFER_LEN]
+            x = net_in[torch.tensor(fr, device=rt.device)] if fr != list(range(fr[0], fr[0] + len(fr))) else net_in[fr[0]:fr[0] + len(fr)]
+            enc.run(x.contiguous(), tap_out=[t.narrow0(c0 * P, len(fr) * P) for t in cache])
+        T = util.INFER_LEN
+        for w in windows:
+            rows = [slot[f] for f in table[w]]
+            if rows == list(range(rows[0], rows[0] + T)):          # one contiguous run: read the cache in place
+                taps = [t.narrow0(rows[0] * P, T * P) for t in cache]
+            else:                                                   # copy the (typically 3) runs of slots into a window buffer
+                taps = [rt.hbuf(f"win_tap{j}", (T * P, C)) for j in range(4)]
+                i = 0
+                while i < T:
+                    k = i
+                    while k + 1 < T and rows[k + 1] == rows[k] + 1:
+                        k += 1
+                    for src, dst in zip(cache, taps):
+                        dst.hi[i * P:(k + 1) * P].copy_(src.hi[rows[i] * P:(rows[k] + 1) * P])
+                        if dst.lo is not None:
+                            dst.lo[i * P:(k + 1) * P].copy_(src.lo[rows[i] * P:(rows[k] + 1) * P])
+                    i = k + 1
+            yield head.run(taps, T, ph, pw, T=T, relu=True).reshape(T, H, W)
 
 
 class DeviceStitcher:
