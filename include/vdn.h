@@ -132,6 +132,16 @@ typedef struct vdn_gemm_desc {
    * 64 bytes of e5m2((v - hi(v)) * 2^10), same token mapping as dst[s]. NULL = not written. Must be NULL for
    * transposed splits.                                                                                            */
   void* dst8[3];
+  /* 8-bit cross-term planes of the GEMM operands themselves (plain A, VDN_F16, K % 64 == 0; all three optional):
+   * A8 u8 [2, M, K] and W8 u8 [2, N, ldb]: plane 0 = e5m2(v), plane 1 = e5m2((v - hi(v)) * 2^10), same row-major shape
+   * as the fp16 operand (lda == K). When both are given, the kernel accumulates A_hi W_hi^T on fp16 MFMAs and the two cross
+   * terms on the block-scaled 8-bit MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) instead of two more fp16 products; A_lo /
+   * W_lo are then not read. out8: the same planes of a half-precision PLAIN output (u8 [2, M, ldc], ldc % 64 == 0),
+   * written next to out / out_lo for the GEMM that consumes it. vdn_pack_weight8 / vdn_layernorm / vdn_flash_attn
+   * produce the planes of weights and of the other activations.                                                    */
+  const void* A8;
+  const void* W8;
+  void* out8;
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
@@ -152,6 +162,7 @@ typedef struct vdn_gemm_tuning {
   int splitk_max;   /* VDN_SPLITK_MAX    most K slices (8)                                                        */
   int min_tiles;    /* VDN_GEMM_MIN_TILES plain-A problems with fewer 128x256 tiles use the 4-wave 128x128 kernel (96) */
   float f128, f192; /* VDN_GEMM_F128/F192 cost factors of the smaller M tiles in pick_bm (1.12, 1.04)             */
+  int x8;           /* VDN_GEMM_X8       1 (default): launches that carry A8 / W8 planes use the 8-bit cross-term kernel (an experiment: slower than the 3-product kernel) */
 } vdn_gemm_tuning;
 int vdn_gemm_get_tuning(vdn_gemm_tuning* out);
 int vdn_gemm_set_tuning(const vdn_gemm_tuning* in);

@@ -958,3 +958,34 @@ def test_pack_weight_abi_against_torch_layouts(rt3):
     assert torch.equal(bp.cpu(), torch.cat([bs[0][rp], bs[1][rp], bs[2]]))
     one = pack.linear(rnd(64, 64, seed=970).to(DEV), torch.float16)  # 1-product modes: no lo plane
     assert one.lo is None
+
+
+@pytest.mark.parametrize("M,N,K", [(2740, 1024, 1024), (1370 * 2 + 77, 3072, 384), (2048, 512, 4096)])
+def test_x8_gemm_cross_terms_on_the_8bit_mfma(rt3, M, N, K, tune):
+    """gemm_x8_kernel: A_hi W_hi^T on fp16 MFMAs + the two cross terms on the block-scaled e5m2 MFMA, from the 8-bit
+    operand planes; ragged M (tile tail), 1 / 6 / 64 slabs; against fp64, against the 3-product kernel, bitwise repeatable."""
+    from vdn import pack, _abi
+    a = rnd(M, K, seed=980)
+    w = rnd(N, K, seed=981, scale=1 / math.sqrt(K))
+    b, g = rnd(N, seed=982), rnd(N, seed=983)
+    x = rnd(M, N, seed=984)
+    ref = (x.double() + (a.double() @ w.double().t() + b.double()) * g.double()).float()
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    A8, W8 = pack.planes8(A), pack.planes8(W)
+    xd = x.clone().to(DEV)
+    rt3.gemm(A, W, M, N, K, out=xd, bias=b.to(DEV), gamma=g.to(DEV), res1=xd, a8=A8, w8=W8)
+    close(xd, ref, 2e-5)
+    x3 = x.clone().to(DEV)
+    rt3.gemm(A, W, M, N, K, out=x3, bias=b.to(DEV), gamma=g.to(DEV), res1=x3)  # three fp16 products
+    close(xd, x3, 2e-5)
+    # bias + GELU -> split planes + the 8-bit planes of the output (what fc1 hands to fc2)
+    oh = rt3.hbuf(f"t_x8_{M}_{N}", (M, N))
+    o8 = torch.zeros(2, M, N, dtype=torch.uint8, device=DEV)
+    rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8, w8=W8, out8=o8)
+    close(oh.float(), F.gelu(a.double() @ w.double().t() + b.double()).float(), 2e-5)
+    want = pack.planes8(oh)
+    assert (o8.int() - want.int()).abs().max() <= 1 and (o8 != want).float().mean() < 1e-3
+    first = (oh.hi.clone(), oh.lo.clone())
+    for _ in range(5):
+        rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8, w8=W8, out8=o8)
+        assert torch.equal(oh.hi, first[0]) and torch.equal(oh.lo, first[1])

@@ -30,6 +30,7 @@ static vdn_gemm_tuning& tuning_rw() {
     v.min_tiles = env_int("VDN_GEMM_MIN_TILES", 96);
     v.f128 = env_float("VDN_GEMM_F128", 1.12f);
     v.f192 = env_float("VDN_GEMM_F192", 1.04f);
+    v.x8 = env_int("VDN_GEMM_X8", 1);
     return v;
   }();
   return t;
@@ -73,6 +74,9 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if (((uintptr_t)d.A_lo | (uintptr_t)d.W_lo | (uintptr_t)d.out_lo) & 15) return VDN_EALIGN;
   if (d.out_lo && (d.out_dt == VDN_F32 || !d.out)) return VDN_EINVAL;
   if ((d.res1 && (d.ldr1 & 3)) || (d.res2 && (d.ldr2 & 3))) return VDN_EALIGN;
+  if (((uintptr_t)d.A8 | (uintptr_t)d.W8 | (uintptr_t)d.out8) & 15) return VDN_EALIGN;
+  if ((d.A8 || d.W8) && (d.dt != VDN_F16 || d.a_mode != VDN_A_PLAIN || (d.K & 63) || d.lda != d.K)) return VDN_EINVAL;
+  if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || !d.out_lo || (d.ldc & 63))) return VDN_EINVAL;
   if (((uintptr_t)d.bias | (uintptr_t)d.gamma | (uintptr_t)d.tab | (uintptr_t)d.res1 | (uintptr_t)d.res2) & 7) return VDN_EALIGN;
   switch (d.store) {
     case VDN_ST_PLAIN:

@@ -117,6 +117,12 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     }
     *(typename H::V4*)((T*)p.out + o) = h;
     *(typename H::V4*)((T*)p.out_lo + o) = l;
+    if (p.out8) {  // 8-bit planes for the consuming GEMM's cross terms: e5m2(v) [M, ldc], then the remainder plane
+      uint8_t* d8 = (uint8_t*)p.out8 + o;
+      const float k = VDN_LO8_SCALE;
+      *(uint32_t*)d8 = pk4_bf8(a[0], a[1], a[2], a[3]);
+      *(uint32_t*)(d8 + (size_t)p.M * p.ldc) = pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]);
+    }
     return;
   } else if constexpr (STORE == VDN_STX_HALF || STORE == VDN_STX_RESHALF1 || STORE == VDN_STX_RESHALF2) {
     // [bias] [relu] [+ split-half residual(s)] -> split half planes, plain rows (the DPT head's convolutions)
@@ -1563,6 +1569,7 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
 }
 
 template <int DT> int big_entry(const vdn_gemm_desc& d, int bm, hipStream_t s);  // defined in gemm_big_*.hip
+int x8_entry(const vdn_gemm_desc& d, hipStream_t s);                             // gemm_x8.hip (fp16 only)
 
 // ---- split-K for convolutions whose tile grid covers a fraction of the chip (include/vdn.h: splitk_ws)
 // second pass: partial sums of the K slices added in slice order, then the SAME straight-line epilogue flavour
@@ -1623,6 +1630,12 @@ inline int pick_bm(int M, int N, int cu_hint) {
 
 template <int DT>
 int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
+  // 8-bit cross terms (gemm_x8.hip): plain A, fp16, K a multiple of 64, enough rows to fill 256 x 256 tiles
+  if constexpr (DT == VDN_F16) {
+    if (d.A8 && d.W8 && d.a_mode == VDN_A_PLAIN && !d.relu_a && !(d.K & 63) && d.N >= 192 && (long)d.M * d.N >= 1024L * 1024 &&
+        tuning().x8 != 0)
+      return x8_entry(d, s);
+  }
   // 8-wave kernels: large problems, and small ones whose deep reduction makes them split-K candidates
   const bool deep = d.splitk_ws && (d.a_mode == VDN_A_CONV3X3 ? d.ldb : d.K) >= 2048 && (long)d.M * d.N >= 32L * 1024;
   if (d.A_lo && d.W_lo && d.N >= 192 && ((long)d.M * d.N >= 256L * 1024 || deep) &&

@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("conv_korder", i32), ("cu_hint", i32),
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("ksplit", i32),
         ("dst8", vp * 3),
+        ("A8", vp), ("W8", vp), ("out8", vp),
     ]
 
 
@@ -44,7 +45,7 @@ class GemmTuning(C.Structure):
     """Mirror of vdn_gemm_tuning (include/vdn.h): process-wide kernel-selection knobs of vdn_gemm."""
     _fields_ = [("force_bm", i32), ("p8", i32), ("no_splitk", i32), ("no_pipe", i32), ("persist", i32), ("splitk_p8", i32),
                 ("cus", i32), ("splitk_occ", i32), ("splitk_max", i32), ("min_tiles", i32), ("f128", C.c_float),
-                ("f192", C.c_float)]
+                ("f192", C.c_float), ("x8", i32)]
 
 
 class VdnError(RuntimeError):

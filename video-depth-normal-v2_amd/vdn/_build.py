@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libvdn_hip.so")
-SOURCES = ["gemm_big_f16.hip", "gemm_big_bf16.hip", "gemm_small_f16.hip", "gemm_small_bf16.hip", "gemm.hip", "attn.hip",
+SOURCES = ["gemm_big_f16.hip", "gemm_big_bf16.hip", "gemm_small_f16.hip", "gemm_small_bf16.hip", "gemm_x8.hip", "gemm.hip", "attn.hip",
            "norm.hip", "spatial.hip", "tail.hip", "pack.hip", "stitch.hip", "refine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

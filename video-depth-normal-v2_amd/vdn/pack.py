@@ -138,6 +138,16 @@ def cat_proj(ws, bs, ropes, half) -> Tuple[torch.Tensor, Optional[torch.Tensor]]
     return out, bias
 
 
+def planes8(t) -> torch.Tensor:
+    """HL [rows, ld] (ld % 64 == 0) -> u8 [2, rows, ld]: e5m2(value) and e5m2(remainder * 2^10), the operand planes of
+    the 8-bit cross-term GEMM (include/vdn.h A8 / W8)."""
+    rows, ld = t.hi.shape
+    assert ld % 64 == 0 and t.lo is not None
+    v8 = t.float().to(torch.float8_e5m2).view(torch.uint8)
+    l8 = (t.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)
+    return torch.stack([v8, l8]).contiguous()
+
+
 def rope_table(side_y: int, side_x: int, dim: int = 64, theta: float = 10000.0, device=None) -> torch.Tensor:
     """(cos, sin) of sam2 compute_axial_cis (position_encoding.py:192-201): f32 [side_y*side_x, dim/2, 2].
     Pairs 0..dim/4-1 rotate with the x coordinate, dim/4..dim/2-1 with y."""

@@ -138,7 +138,8 @@ class Runtime:
              out: Optional[torch.Tensor] = None, ldc: Optional[int] = None, bias=None, act: int = 0, gamma=None,
              rowadd=None, tab=None, tab_mod: int = 0, tab_off: int = 0, res1=None, ldr1=None, res2=None, ldr2=None,
              conv: Optional[dict] = None, relu_a: bool = False, store: int = abi.ST_PLAIN, row_group: int = 0,
-             row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None, tag: Optional[str] = None):
+             row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None, tag: Optional[str] = None,
+             a8: Optional[torch.Tensor] = None, w8: Optional[torch.Tensor] = None, out8: Optional[torch.Tensor] = None):
         d = abi.GemmDesc()
         d.dt = self.dt
         d.M, d.N, d.K = M, N, K
@@ -196,6 +197,10 @@ class Runtime:
             d.ck, d.cout = convt["k"], convt["cout"]
             d.cB, d.cH, d.cW = convt["B"], convt["H"], convt["W"]
         d.zeros = self.zeros.data_ptr()
+        if a8 is not None and w8 is not None:  # 8-bit cross-term planes of both operands (include/vdn.h A8 / W8)
+            d.A8, d.W8 = a8.data_ptr(), w8.data_ptr()
+        if out8 is not None:
+            d.out8 = out8.data_ptr()
         d.cu_hint = self.cu_hint
         if self.split:  # split-K scratch for launches whose tile grid covers a fraction of the chip (include/vdn.h)
             ws = self.buf("splitk_ws", (32 * 1024 * 1024,), torch.float32)
