@@ -176,9 +176,13 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   //   this loop 4.05 us per slab; a ping-pong variant (two wave groups one barrier apart, refill two phases later,
   //   vmcnt(8) = 64 KiB in flight) 5.3 us, of which DMA-only 3.3 us and MFMA + fragment reads only 2.7 us (ablated builds).
   //   The feed is LDS-capacity bound: bytes in flight / DMA latency (~1.65 us under load) = 39 GB/s per CU with 64 KiB,
-  //   ~58 GB/s with 96 KiB, i.e. >= 2.2 us per 128-KiB slab — a slab-sized LDS leaves no room to prefetch deeper. Three
-  //   bytes per element (deriving e5m2(X) from the fp16 fragments in registers) would lower that to ~1.7 us; not built.
-  //   The kernel is therefore kept as a tested experiment (engines do not pass A8 / W8): it does not beat the 3-product one.
+  //   ~58 GB/s with 96 KiB, i.e. >= 2.2 us per 128-KiB slab — a slab-sized LDS leaves no room to prefetch deeper.
+  //   A 3-bytes-per-element variant was also built and timed (e5m2(X_hi) derived from the fp16 fragments in registers,
+  //   remainder planes stored in the MFMA's slot order, 96 KiB per slab in a 5-slot ring with 128 KiB in flight): 3.86 us
+  //   per slab — with the feed out of the way the loop is bound by its own structure (6 barriers and 36 fragment reads per
+  //   slab around 48 MFMAs per wave), not by bytes. Both lose to gemm_x3_p8_kernel, whose 8-phase ping-pong hides exactly
+  //   that; an 8-bit kernel would need the same treatment on a 3-phase slab. Kept as a tested experiment (the engines do
+  //   not pass A8 / W8).
   const int nslab = p.K >> 6;
   constexpr std::integral_constant<int, 0> P0{};
   constexpr std::integral_constant<int, 1> P1{};
