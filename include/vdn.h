@@ -260,13 +260,16 @@ int vdn_addtab_cast(int dt, const float* x, const float* tab, int tab_div, int t
                     size_t rows, int C, vdn_stream stream);
 
 /* Streaming temporal attention over a PROJECTED key/value cache (video_depth_stream.py:133-158,
- * motion_module.py:255-277). entries: device array of T pointers, oldest first, each to one cached
- * frame's f32 [HW, 3c] = (q | k | v) projections of its LayerNorm-ed hidden state WITHOUT the frame-position term;
- * pe_q / pe_k / pe_v: f32 [>= T, c] = PositionalEncoding.pe @ W_{q,k,v}^T (added on load: W(x + pe) = Wx + W pe).
- * Only the newest frame (entries[T-1], position T-1) queries; 8 heads of c/8; out: half planes [HW, c] (out_lo may
- * be NULL). c in {64, 128, 192, 256, 384, 512, 768, 1024}, T <= 32.                                                         */
-int vdn_temporal_attn_last(int dt, const void* const* entries, int T, int HW, int c, const float* pe_q, const float* pe_k,
-                           const float* pe_v, float scale, void* out, void* out_lo, vdn_stream stream);
+ * motion_module.py:255-277). pool: a caller-owned ring of frame slots, f32 [slots, slot_stride >= HW*3c];
+ * a slot holds one cached frame's [HW, 3c] = (q | k | v) projections of its LayerNorm-ed hidden state WITHOUT the
+ * frame-position term. slots: HOST array of the T ring-slot indices of the window, oldest first (copied into the launch
+ * arguments: no pointer table in HBM, nothing allocated per step). pe_q / pe_k / pe_v: f32 [>= T, c] =
+ * PositionalEncoding.pe @ W_{q,k,v}^T (added on load: W(x + pe) = Wx + W pe). Only the newest frame (slots[T-1],
+ * position T-1) queries; 8 heads of c/8; out: half planes [HW, c] (out_lo may be NULL).
+ * c in {64, 128, 192, 256, 384, 512, 768, 1024}, T <= 32.                                                            */
+int vdn_temporal_attn_last(int dt, const float* pool, size_t slot_stride, const int32_t* slots, int T, int HW, int c,
+                           const float* pe_q, const float* pe_k, const float* pe_v, float scale, void* out, void* out_lo,
+                           vdn_stream stream);
 
 /* Device-side window stitcher of VideoDepthAnything.infer_video_depth (video_depth.py:118-156):
  * vdn_stitch_fit   — closed-form least-squares scale/shift of `pred` onto `target` over n f32 values with an all-ones

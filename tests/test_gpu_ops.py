@@ -751,7 +751,13 @@ def test_temporal_attention_last_frame_over_projected_cache(rt3, T, HW, c):
     entries = [torch.cat([st.double() @ w.double().t() for w in (wq, wk, wv)], dim=1).float().to(DEV).contiguous() for st in states]
     tabs = [(pe.double() @ w.double().t()).float().to(DEV).contiguous() for w in (wq, wk, wv)]
     out = rt3.hbuf(f"t_tal_{T}_{c}", (HW, c))
-    rt3.temporal_attn_last(entries, tabs[0], tabs[1], tabs[2], out, HW, c, (c // 8) ** -0.5)
+    # the frames sit in scattered slots of a ring (as the streaming driver leaves them); the window lists them oldest first
+    nslots = T + 5
+    slots = torch.randperm(nslots, generator=g)[:T].tolist()
+    pool = torch.full((nslots, HW, 3 * c), float("nan"), device=DEV)
+    for t in range(T):
+        pool[slots[t]] = entries[t]
+    rt3.temporal_attn_last(pool, slots, tabs[0], tabs[1], tabs[2], out, HW, c, (c // 8) ** -0.5)
     close(out.float(), ref, 5e-6)
 
 
@@ -989,3 +995,20 @@ def test_x8_gemm_cross_terms_on_the_8bit_mfma(rt3, M, N, K, tune):
     for _ in range(5):
         rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8, w8=W8, out8=o8)
         assert torch.equal(oh.hi, first[0]) and torch.equal(oh.lo, first[1])
+
+
+def test_nan_in_a_conv_input_reaches_the_output(rt3):
+    """The optional ReLU of the plane-output conv epilogues must not swallow NaNs (fmaxf(NaN, 0) = 0 would hide a
+    consumed-before-written element from the VDN_POISON screen and differs from torch.relu)."""
+    from vdn import pack, _abi
+    B, H, W, Ci, Co = 1, 20, 20, 64, 256
+    x = rnd(B * H * W, Ci, seed=990)
+    x[137, 5] = float("nan")
+    w = rnd(Co, Ci, 3, 3, seed=991, scale=1 / math.sqrt(9 * Ci))
+    xa = rt3.to_half(x.to(DEV))
+    for act in (_abi.ACT_RELU, _abi.ACT_NONE):
+        out = rt3.hbuf("t_nan_o", (B * H * W, Co))
+        rt3.gemm(xa, pack.conv3x3(w.to(DEV), rt3.prec), B * H * W, Co, 9 * Ci, out=out, bias=rnd(Co, seed=992).to(DEV), act=act,
+                 conv=dict(B=B, H=H, W=W, C=Ci, OH=H, OW=W, stride=1))
+        bad = torch.isnan(out.float()).any(dim=1).reshape(H, W).cpu()
+        assert int(bad.sum()) == 9 and bool(bad[5:8, 16:19].all())  # the 3x3 neighbourhood of pixel 137 = (6, 17)

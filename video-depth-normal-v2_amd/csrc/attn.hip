@@ -584,8 +584,11 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<
 // (c/8 channels) is 8 consecutive lanes; scores are reduced inside the 8-lane group, softmax over the
 // <= 32 frames in registers, output written as operand planes for the out-projection GEMM. HBM-bound:
 // T x 2c f32 per pixel are read once.
+struct SlotTable { int s[32]; };  // ring slots of the window's frames, oldest first; passed BY VALUE (no table in HBM)
+
 template <int DT, int CPL /*channels per lane: c / 64*/>
-__global__ __launch_bounds__(256) void temporal_last_kernel(const float* const* __restrict__ entries, int T, int HW, int c,
+__global__ __launch_bounds__(256) void temporal_last_kernel(const float* __restrict__ pool, size_t slot_stride, SlotTable tab,
+                                                            int T, int HW, int c,
                                                             const float* __restrict__ peq, const float* __restrict__ pek,
                                                             const float* __restrict__ pev, float scale,
                                                             typename Half<DT>::T* __restrict__ out,
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256) void temporal_last_kernel(const float* const* 
   const size_t row = (size_t)px * 3 * c;
   float q[CPL];
   {
-    const float* qn = entries[T - 1] + row + ch;  // the newest frame is the query, at position T-1
+    const float* qn = pool + (size_t)tab.s[T - 1] * slot_stride + row + ch;  // the newest frame is the query, at position T-1
 #pragma unroll
     for (int e = 0; e < CPL; ++e) q[e] = (qn[e] + peq[(size_t)(T - 1) * c + ch + e]) * scale;
   }
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(256) void temporal_last_kernel(const float* const* 
   for (int t = 0; t < 32; ++t) {
     sc[t] = -INFINITY;
     if (t < T) {
-      const float* kt = entries[t] + row + c + ch;
+      const float* kt = pool + (size_t)tab.s[t] * slot_stride + row + c + ch;
       const float* pk = pek + (size_t)t * c + ch;
       float d = 0.f;
 #pragma unroll
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void temporal_last_kernel(const float* const* 
 #pragma unroll
   for (int t = 0; t < 32; ++t) {
     if (t < T) {
-      const float* vt = entries[t] + row + 2 * c + ch;
+      const float* vt = pool + (size_t)tab.s[t] * slot_stride + row + 2 * c + ch;
       const float* pv = pev + (size_t)t * c + ch;
       const float p = sc[t] * inv;
 #pragma unroll
@@ -738,15 +741,21 @@ extern "C" int vdn_temporal_attn(int dt, const void* qkv, void* out, const void*
   return VDN_EUNSUPPORTED;
 }
 
-extern "C" int vdn_temporal_attn_last(int dt, const void* const* entries, int T, int HW, int c, const float* pe_q,
-                                      const float* pe_k, const float* pe_v, float scale, void* out, void* out_lo,
-                                      vdn_stream stream) {
-  if (!entries || !pe_q || !pe_k || !pe_v || !out || T < 1 || T > 32 || HW <= 0) return VDN_EINVAL;
+extern "C" int vdn_temporal_attn_last(int dt, const float* pool, size_t slot_stride, const int32_t* slots, int T, int HW,
+                                      int c, const float* pe_q, const float* pe_k, const float* pe_v, float scale,
+                                      void* out, void* out_lo, vdn_stream stream) {
+  if (!pool || !slots || !pe_q || !pe_k || !pe_v || !out || T < 1 || T > 32 || HW <= 0) return VDN_EINVAL;
+  if (slot_stride < (size_t)HW * 3 * c) return VDN_EINVAL;
+  SlotTable tab;
+  for (int t = 0; t < 32; ++t) {
+    tab.s[t] = t < T ? slots[t] : 0;
+    if (tab.s[t] < 0) return VDN_EINVAL;
+  }
   if (c <= 0 || (c & 63) || c > 1024) return VDN_EUNSUPPORTED;  // 8 heads of c/8 = 8 lanes x c/64 channels
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((HW + 3) / 4), block(256);
 #define VDN_TL(DT_, CPL_)                                                                                                  \
-  hipLaunchKernelGGL((temporal_last_kernel<DT_, CPL_>), grid, block, 0, s, (const float* const*)entries, T, HW, c, pe_q, pe_k, \
+  hipLaunchKernelGGL((temporal_last_kernel<DT_, CPL_>), grid, block, 0, s, pool, slot_stride, tab, T, HW, c, pe_q, pe_k, \
                      pe_v, scale, (typename Half<DT_>::T*)out, (typename Half<DT_>::T*)out_lo)
 #define VDN_TL_C(DT_)                                  \
   switch (c) {                                         \

@@ -98,7 +98,8 @@ EXPORTS = {
     "vdn_dwconv7": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
     "vdn_addtab_cast": (C.c_int, [C.c_int, fp, fp, C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]),
     "vdn_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_size_t, vp]),
-    "vdn_temporal_attn_last": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_float, vp, vp, vp]),
+    "vdn_temporal_attn_last": (C.c_int, [C.c_int, fp, C.c_size_t, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, fp, fp, fp,
+                                         C.c_float, vp, vp, vp]),
     "vdn_frame_median_workspace_bytes": (C.c_size_t, [C.c_int]),
     "vdn_frame_median": (C.c_int, [fp, C.c_int, C.c_size_t, fp, vp, vp]),
     "vdn_refine_scale": (C.c_int, [fp, fp, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, vp]),

@@ -181,27 +181,29 @@ class TemporalEngine:
         """x half [(b f) * HW, c] (NHWC frames) -> same shape."""
         return self.out(self.core(self.gn(x, B * T, HW), B, T, HW), x, B * T * HW)
 
-    def run_stream(self, x, HW: int, cached, new_entries: list):
+    STREAM_SLOTS = 44  # the reference keeps at most 42 cached frames (video_depth_stream.py:155-158) + the new one
+
+    def run_stream(self, x, HW: int, window_slots, new_slot: int):
         """Streaming step (video_depth_stream.py:76-160, motion_module.py:255-277): x is ONE frame [HW, c].
-        `cached` is None for the first frame (attention over the frame itself) or a list, per attention block,
-        of the 31 cached entries (oldest first); the new frame's entries are appended to `new_entries`.
-        An entry is the frame's q|k|v PROJECTION without the position term (f32 [HW, 3c]): the
+        `window_slots`: ring slots of the (up to 31) cached frames this step attends over, oldest first; the new frame's
+        projections go to ring slot `new_slot` and it attends last.
+        A slot holds the frame's q|k|v PROJECTION without the position term (f32 [HW, 3c]): the
         reference caches the LayerNorm output and re-projects all 32 frames with the sliding window's positions
         every step; here each frame is projected once and the positions enter as [T, c] tables inside
-        `vdn_temporal_attn_last` (W(x + pe) = Wx + W pe), which also computes the newest frame's query only."""
+        `vdn_temporal_attn_last` (W(x + pe) = Wx + W pe), which also computes the newest frame's query only.
+        The two attention blocks own one fixed ring each (nothing is allocated per step, no pointer table)."""
         rt, c = self.rt, self.c
         g = self.gn(x, 1, HW)
         hs = rt.fbuf("ts_h", (HW, c))
         rt.gemm(g, self.w_in, HW, c, c, bias=self.b_in, out=hs)
         nh = rt.hbuf("ts_nh", (HW, c))
         a = rt.hbuf("ts_a", (HW, c))
+        slots = list(window_slots) + [new_slot]
         for j, at in enumerate(self.att):
+            pool = rt.fbuf(f"ts_pool{self.idx}_{j}", (self.STREAM_SLOTS, HW, 3 * c))
             rt.layernorm(hs, HW, c, at["nw"], at["nb"], 1e-5, out_h=nh)
-            entry = torch.empty((HW, 3 * c), dtype=torch.float32, device=rt.device)
-            rt.gemm(nh, at["wqkv"], HW, 3 * c, c, out=entry)
-            new_entries.append(entry)
-            window = [entry] if cached is None else list(cached[j]) + [entry]
-            rt.temporal_attn_last(window, at["pe_q"], at["pe_k"], at["pe_v"], a, HW, c, (c // 8) ** -0.5)
+            rt.gemm(nh, at["wqkv"], HW, 3 * c, c, out=pool[new_slot])
+            rt.temporal_attn_last(pool, slots, at["pe_q"], at["pe_k"], at["pe_v"], a, HW, c, (c // 8) ** -0.5)
             rt.gemm(a, at["wo"], HW, c, c, bias=at["bo"], res1=hs, out=hs)
         n = rt.hbuf("ts_n", (HW, c))
         rt.layernorm(hs, HW, c, self.fnw, self.fnb, 1e-5, out_h=n)
@@ -320,9 +322,8 @@ class DPTEngine:
         l3 = pr[2]
         l4 = self._conv3(pr[3], self.rs3[0], Bf, ph, pw, oc[3], oc[3], "l4", stride=2, bias=self.rs3[1])
         def tm(i, x, hw):
-            if stream is not None:  # streaming: one new frame against the cached states of 31 earlier ones
-                cached = None if stream["cached"] is None else stream["cached"][2 * i: 2 * i + 2]
-                return self.temporal[i].run_stream(x, hw, cached, stream["new"])
+            if stream is not None:  # streaming: one new frame against the cached projections of up to 31 earlier ones
+                return self.temporal[i].run_stream(x, hw, stream["window"], stream["new"])
             if exch is not None:  # frame-sharded window: Bf == this rank's frames of ONE clip
                 return self.temporal[i].run_sharded(x, exch, hw)
             return self.temporal[i].run(x, Bf // T, T, hw)

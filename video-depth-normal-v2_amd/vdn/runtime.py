@@ -227,14 +227,14 @@ class Runtime:
         (qkv, ql), (out, ol) = _hl(qkv), _hl(out)
         self._launch(abi.lib.vdn_temporal_attn, self.dt, qkv.data_ptr(), out.data_ptr(), ql, ol, Bv, T, D, c, heads, scale)
 
-    def temporal_attn_last(self, entries, pe_q, pe_k, pe_v, out, HW: int, c: int, scale: float):
-        """Newest frame attends over the projected cache `entries` (list of f32 [HW, 3c], oldest first)."""
-        T = len(entries)
-        ptrs = torch.tensor([t.data_ptr() for t in entries], dtype=torch.int64).to(self.device)
-        self._keep_ptrs = (ptrs, entries)  # alive until the next call has been enqueued
+    def temporal_attn_last(self, pool: torch.Tensor, slots, pe_q, pe_k, pe_v, out, HW: int, c: int, scale: float):
+        """Newest frame attends over the projected cache: `pool` f32 [ring slots, HW, 3c], `slots` the window's ring-slot
+        indices, oldest first (host ints: they travel in the launch arguments)."""
+        T = len(slots)
+        tab = (C.c_int32 * T)(*slots)
         (out, ol) = _hl(out)
-        self._launch(abi.lib.vdn_temporal_attn_last, self.dt, ptrs.data_ptr(), T, HW, c, pe_q.data_ptr(), pe_k.data_ptr(),
-                     pe_v.data_ptr(), scale, out.data_ptr(), ol)
+        self._launch(abi.lib.vdn_temporal_attn_last, self.dt, pool.data_ptr(), pool.stride(0), tab, T, HW, c, pe_q.data_ptr(),
+                     pe_k.data_ptr(), pe_v.data_ptr(), scale, out.data_ptr(), ol)
 
     def groupnorm(self, x, y, F: int, HW: int, Cn: int, groups: int, w, b, eps: float):
         nsplit = 16 if HW >= 1024 else 4

@@ -58,25 +58,29 @@ class VideoDepthAnything(_EngineOwner):
         rt, enc, head = e["rt"], e["enc"], e["head"]
         st = getattr(self, "_stream", None)
         if st is None:
-            st = self._stream = dict(cache=[], ids=[], id=-1, gap=(INFER_LEN - OVERLAP) * 2 - 1 - (OVERLAP - INTERP_LEN))
+            # cache / ids: the reference's lists (one entry per cached frame), here holding RING SLOT numbers: a frame's 8
+            # projection sets (2 attention blocks x 4 temporal modules) live in slot k of 8 fixed rings (TemporalEngine)
+            st = self._stream = dict(cache=[], ids=[], id=-1, gap=(INFER_LEN - OVERLAP) * 2 - 1 - (OVERLAP - INTERP_LEN),
+                                     free=list(range(head.temporal[0].STREAM_SLOTS)))
         st["id"] += 1
         _, _, _, H, W = x.shape
         xf = x.to(device=rt.device, dtype=torch.float32).reshape(1, 3, H, W).contiguous()
         taps, _, (ph, pw) = enc.run(xf)
-        new = []
+        new = st["free"].pop(0)
         if not st["cache"]:
-            depth = head.run(taps, 1, ph, pw, T=1, relu=not _pre_relu, stream=dict(cached=None, new=new))
+            depth = head.run(taps, 1, ph, pw, T=1, relu=not _pre_relu, stream=dict(window=[], new=new))
             st["cache"] = [new] * INFER_LEN
             st["ids"].extend([0] * (INFER_LEN - 1))
         else:
             cur = st["cache"][0:2] + st["cache"][-INFER_LEN + 3:]
-            cached = [[h[i] for h in cur] for i in range(len(cur[0]))]
-            depth = head.run(taps, 1, ph, pw, T=1, relu=not _pre_relu, stream=dict(cached=cached, new=new))
+            depth = head.run(taps, 1, ph, pw, T=1, relu=not _pre_relu, stream=dict(window=cur, new=new))
             st["cache"].append(new)
         st["ids"].append(st["id"])
         if st["id"] + INFER_LEN > st["gap"] + 1:
             del st["ids"][1]
-            del st["cache"][1]
+            gone = st["cache"].pop(1)
+            if gone not in st["cache"]:  # the first frame's slot is referenced 32 times at the start
+                st["free"].append(gone)
         return depth.reshape(H, W).clone()
 
     @torch.no_grad()
