@@ -34,13 +34,43 @@ for (B, H, nq, nk) in ((8, 16, 1370, 1370), (4, 16, 1369, 8214), (2, 6, 150, 200
     k = rt.to_half(torch.randn(B * H, kp, 64, device="cuda"))
     v = rt.to_half(torch.randn(B * H, 64, kp, device="cuda"))
     o = rt.hbuf(f"rs_o{nq}_{nk}", (B * nq, H * 64))
-    rt.flash_attn(q, k, v, o, B, H, nq, qp, nk, kp, 0.125)
-    h0, l0 = o.hi.clone(), o.lo.clone()
-    diff = 0
-    for _ in range(reps):
-        rt.flash_attn(q, k, v, o, B, H, nq, qp, nk, kp, 0.125)
-        diff += int(not (torch.equal(o.hi, h0) and torch.equal(o.lo, l0)))
-    bad += diff
-    print(f"attn B={B} H={H} nq={nq} nk={nk}: {diff} of {reps} runs differ", flush=True)
+
+    def planes8(t):  # the 8-bit planes the projection epilogue would have written (score cross terms on the e5m2 MFMA)
+        return torch.cat([t.float().to(torch.float8_e5m2).view(torch.uint8),
+                          (t.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)], dim=-1).contiguous()
+
+    for tag, kw in (("3-product scores", {}), ("8-bit cross terms", dict(q8=planes8(q), k8=planes8(k)))):
+        rt.flash_attn(q, k, v, o, B, H, nq, qp, nk, kp, 0.125, **kw)
+        h0, l0 = o.hi.clone(), o.lo.clone()
+        diff = 0
+        for _ in range(reps):
+            rt.flash_attn(q, k, v, o, B, H, nq, qp, nk, kp, 0.125, **kw)
+            diff += int(not (torch.equal(o.hi, h0) and torch.equal(o.lo, l0)))
+        bad += diff
+        print(f"attn ({tag}) B={B} H={H} nq={nq} nk={nk}: {diff} of {reps} runs differ", flush=True)
+# fused depth tail (LDS-DMA source patch + register-resident weights) and the persistent LayerNorm
+x = torch.randn(8 * 296 * 296, 128, device="cuda")
+w = pack.conv3x3_taps(torch.randn(32, 128, 3, 3, device="cuda") / math.sqrt(9 * 128), rt.prec)
+b2, w1 = torch.randn(32, device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.3
+d = torch.empty(8, 518, 518, device="cuda")
+rt.depth_tail(x, w, b2, w1, 0.2, d, 8, 296, 296, 128, 518, 518, True)
+d0 = d.clone()
+diff = 0
+for _ in range(reps // 4):
+    rt.depth_tail(x, w, b2, w1, 0.2, d, 8, 296, 296, 128, 518, 518, True)
+    diff += int(not torch.equal(d, d0))
+bad += diff
+print(f"depth_tail B=8 296->518: {diff} of {reps // 4} runs differ", flush=True)
+t = torch.randn(10960, 1024, device="cuda")
+g, be = torch.randn(1024, device="cuda"), torch.randn(1024, device="cuda")
+oh = rt.hbuf("rs_ln", (10960, 1024))
+rt.layernorm(t, 10960, 1024, g, be, 1e-6, out_h=oh)
+h0, l0 = oh.hi.clone(), oh.lo.clone()
+diff = 0
+for _ in range(reps):
+    rt.layernorm(t, 10960, 1024, g, be, 1e-6, out_h=oh)
+    diff += int(not (torch.equal(oh.hi, h0) and torch.equal(oh.lo, l0)))
+bad += diff
+print(f"layernorm 10960 x 1024: {diff} of {reps} runs differ", flush=True)
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
 sys.exit(1 if bad else 0)
