@@ -91,6 +91,9 @@ def parse_args(argv=None):
     ap.add_argument("--stub", action="store_true",
                     help="plumbing rehearsal without a GPU: gloo backend, CPU tensors, a stand-in network "
                          "(tests/test_dist.py); never a performance number")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path with the real kernels on a one-GPU box: every rank on cuda:0, gloo "
+                         "backend with host-staged collectives (vdn/dist.py); never a performance number")
     a = ap.parse_args(argv)
     if a.workload is None:
         a.workload = "stream" if a.gpus == 1 else "video"
@@ -170,7 +173,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU "
                  f"(python bench.py --gpus N starts them itself)")
@@ -183,7 +186,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.stub:
+        if a.stub or a.shared_gpu:
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
@@ -285,7 +288,7 @@ def main():
             ev += rt.timing or []
             rt.timing = None
         if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=("cpu" if a.shared_gpu else dev), dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, ev
@@ -334,7 +337,8 @@ def main():
         "dtype": prec_name, "data": "synthetic",
         "config": {"workload": workload, "frames_per_step_per_gpu": frames_per_step if not strong else frames_per_step / n_gpus,
                    "lanes": lanes, "precision": prec_name, "ranks": n_gpus,
-                   "backend": ("gloo (stub rehearsal on CPU)" if a.stub else ("nccl (RCCL)" if dist is not None else "none")),
+                   "backend": ("gloo (stub rehearsal on CPU)" if a.stub else "gloo (ranks share one GPU: rehearsal)" if a.shared_gpu and dist is not None
+                               else ("nccl (RCCL)" if dist is not None else "none")),
                    "precision_note": "f16x3 = fp16 hi/lo planes, 3 MFMA products per term (fp32-faithful, parity <=1e-3)"},
     }
     if strong:
@@ -351,7 +355,8 @@ def main():
         if lin:
             tot_ms, tot_fl = sum(t for t, _ in lin), sum(f for _, f in lin)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            traffic, traffic_src = _pmc_traffic(prec_name)
+            # the PMC passes (tools/pmc_traffic.sh) ran the batch-8 stream workload: their per-launch bytes describe that launch size only
+            traffic, traffic_src = _pmc_traffic(prec_name) if (a.workload == "stream" and a.batch == 8 and enc == "vitl") else (None, None)
             out["roofline"] = {
                 "bound": "mfma", "kernel": "gemm_x3_p8_kernel<256x256x32> (fc1) / gemm_x3_big_kernel<192x256x32> (qkv, proj, fc2): the 4 encoder linears" if nprod == 3 else "gemm_kernel<128x128x64> on the 4 encoder linears (qkv, proj, fc1, fc2)",
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),

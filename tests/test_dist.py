@@ -73,13 +73,15 @@ def _reference_clip(frames):
     return util.stitch(dl, len(frames))
 
 
-def _worker_hybrid(rank, world, port, out, n):
+def _worker_hybrid(rank, world, port, out, n, staged=False):
     """world 2, 50 frames = 3 windows: one full round of whole windows + the third window frame-sharded over both
     ranks. world 3, 20 frames = 1 window: sharded over ranks 0-1, rank 2 owns nothing (the idle-rank path)."""
     _init(rank, world, port)
     import bench
     from vdn import synth
+    import vdn.dist
     from vdn.dist import infer_video_depth_sharded, plan_schedule
+    vdn.dist._FORCE_STAGING = staged   # the byte staging a gloo group applies to device tensors (shared-GPU rehearsal)
     frames = synth.frames_u8(7, n, 28, 42)
     m = bench._StubVideoModel()
     d, fps = infer_video_depth_sharded(m, frames, 30, input_size=28, all_ranks=True)
@@ -103,14 +105,16 @@ def test_two_rank_exchange_and_plane_staging(port):
     assert dict(out) == {0: True, 1: True}
 
 
-@pytest.mark.parametrize("world,n,port,expect", [
-    (2, 50, 29612, [(0, 0, 1), (1, 1, 1), (2, 0, 2)]),
-    (3, 20, 29613, [(0, 0, 2)]),
+@pytest.mark.parametrize("world,n,port,expect,staged", [
+    (2, 50, 29612, [(0, 0, 1), (1, 1, 1), (2, 0, 2)], False),
+    (3, 20, 29613, [(0, 0, 2)], False),
+    (2, 50, 29614, [(0, 0, 1), (1, 1, 1), (2, 0, 2)], True),
+    (3, 20, 29615, [(0, 0, 2)], True),
 ])
-def test_hybrid_schedule_driver_gloo(world, n, port, expect):
+def test_hybrid_schedule_driver_gloo(world, n, port, expect, staged):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker_hybrid, args=(world, port, out, n), nprocs=world, join=True)
+    mp.spawn(_worker_hybrid, args=(world, port, out, n, staged), nprocs=world, join=True)
     for r in range(world):
         assert out[r][0] is True, r
         assert [tuple(j) for j in out[r][1]] == expect

@@ -42,6 +42,61 @@ def rank(group=None) -> int:
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
+# --------------------------------------------------------------------------------------------- collectives
+def _staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves host memory only. Device tensors under a gloo group (the shared-GPU rehearsal of the N > 1 path on
+    a one-GPU box: tools/dist_rehearsal.py, `bench.py --shared-gpu`) are staged through the host as bytes; under
+    nccl (= RCCL, the production backend) and for CPU tensors the collective gets the tensor itself."""
+    return (t.is_cuda or _FORCE_STAGING) and dist.get_backend(group) == "gloo"
+
+
+_FORCE_STAGING = False   # tests/test_dist.py: run the byte staging on CPU tensors too
+
+
+def _row_bytes(t: torch.Tensor) -> int:
+    return int(np.prod(t.shape[1:], dtype=np.int64)) * t.element_size()
+
+
+def _bytes(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous().reshape(t.shape[0], _row_bytes(t) // t.element_size()).view(torch.uint8).cpu()
+
+
+def _unbytes(dst: torch.Tensor, host: torch.Tensor):
+    dst.copy_(host.to(dst.device).view(dst.dtype).reshape(dst.shape))
+
+
+def all_to_all(recv: torch.Tensor, send: torch.Tensor, out_split=None, in_split=None, group=None):
+    """dist.all_to_all_single over dim 0 (row counts in the split lists)."""
+    if not _staged(send, group):
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        return
+    hs = _bytes(send)
+    hr = torch.empty((recv.shape[0], _row_bytes(recv)), dtype=torch.uint8)
+    dist.all_to_all_single(hr, hs, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    _unbytes(recv, hr)
+
+
+def gather_to(t: torch.Tensor, parts, dst: int = 0, group=None):
+    if not _staged(t, group):
+        dist.gather(t, parts, dst=dst, group=group)
+        return
+    h = _bytes(t)
+    hp = [torch.empty_like(h) for _ in parts] if parts is not None else None
+    dist.gather(h, hp, dst=dst, group=group)
+    if parts is not None:
+        for p_, h_ in zip(parts, hp):
+            _unbytes(p_, h_)
+
+
+def broadcast_from(t: torch.Tensor, src: int = 0, group=None):
+    if not _staged(t, group):
+        dist.broadcast(t, src=src, group=group)
+        return
+    h = _bytes(t)
+    dist.broadcast(h, src=src, group=group)
+    _unbytes(t, h)
+
+
 # --------------------------------------------------------------------------------------------- schedule
 def window_owner(n_windows: int, nranks: int) -> List[int]:
     """Plain round-robin (window w on rank w % nranks); kept for callers that want whole windows only."""
@@ -132,7 +187,7 @@ def exchange_taps(planes: List[torch.Tensor], rows_per_frame: int, local: List[i
             sbuf[i * rows_per_frame:(i + 1) * rows_per_frame].copy_(pl[lpos[f] * rows_per_frame:(lpos[f] + 1) * rows_per_frame])
         rbuf = pl.new_empty((sum(out_split), C))
         if P > 1:
-            dist.all_to_all_single(rbuf, sbuf, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+            all_to_all(rbuf, sbuf, out_split, in_split, group)
         else:
             rbuf.copy_(sbuf)
         got.append(rbuf)
@@ -236,7 +291,7 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
         slab[: cat.shape[0]].copy_(cat)
     if P > 1:
         parts = [torch.empty_like(slab) for _ in range(P)] if r == 0 else None
-        dist.gather(slab, parts, dst=0)
+        gather_to(slab, parts, dst=0)
     else:
         parts = [slab]
     out = None
@@ -262,7 +317,7 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
         if r != 0:
             out = torch.empty((n, fh, fw), dtype=torch.float32, device=dev)
         out = out.contiguous()
-        dist.broadcast(out, src=0)
+        broadcast_from(out, src=0)
     return (None if out is None else out.cpu().numpy()), target_fps
 
 
@@ -297,7 +352,7 @@ class FrameShardExchange:
         if full < P and HW > full * HWp:
             send[full, :, :HW - full * HWp].copy_(x[:, full * HWp:])
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
+        all_to_all(recv, send, group=self.group)
         return recv.reshape(P * Tl, HWp, c)  # rank-major == frame order (rank q owns frames q*Tl..)
 
     def pixels_to_frames(self, y: torch.Tensor, HW: int) -> torch.Tensor:
@@ -310,7 +365,7 @@ class FrameShardExchange:
         if not send.is_contiguous():
             send = send.contiguous()
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
+        all_to_all(recv, send, group=self.group)
         # recv[q] = my frames' pixel shard q
         out = y.new_empty((self.Tl, HW, c))
         full = HW // HWp
