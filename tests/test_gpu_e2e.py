@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import GOLD, inputs, rel_l2, sample_idx, synth_sd
+from common import GOLD, inputs, rel_l2, sample_idx, stats, synth_sd
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -67,6 +67,44 @@ def test_A_vitl_518_stream_fill_and_evict():
     """BASELINE configs[1] at batch 1: ViT-L, 8 frames on one memory bank — every depth S = 0..6, then one eviction —
     against the fixture written by the imported reference (frames 0, 1, 6, 7 kept)."""
     _stream_A("A_vitl_518", "vitl", oracle_steps=1)
+
+
+def test_A_vitb_266_stream():
+    """ViT-B (12 blocks, 12 heads, taps 2/5/8/11, DPT features 128): three frames on one memory bank against the fixture
+    written by the imported reference."""
+    _stream_A("A_vitb_266", "vitb", oracle_steps=2)
+
+
+@pytest.mark.parametrize("name,enc", [("G_vits_392", "vits"), ("A_vitb_266", "vitb")])
+def test_stage_fixtures_vit_block_and_dpt_paths(name, enc):
+    """SURVEY.md §8c fixtures G2 and G4, taken with forward hooks on the imported reference: the token stream entering and
+    leaving ViT block 0 and leaving the last block (patch embed + pos-embed, one full block, the whole stack), the four
+    FeatureFusionBlock outputs path_4..path_1 and output_conv1 — so a regression in one DPT stage shows at that stage
+    and not only as an error of the final map. 1024 sampled values (NHWC order) and mean/std per tensor."""
+    import vdn
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    B, steps, H, W, _, _ = [int(v) for v in g["meta"]]
+    model = _product("A", enc)
+    e = model._engines()
+    rt, toks = e["rt"], {}
+    e["enc"].probe = lambda i, tok: toks.__setitem__(i, tok.float().cpu().clone())
+    x = inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
+    depth, F, ph = vdn.modules.ENCODERS[enc]["depth"], vdn.MODEL_CONFIGS[enc]["features"], H // 14
+    for t in range(steps):
+        model.forward(x[t].cuda())
+        if f"blk0_in_samp_{t}" not in g.files:
+            continue
+        got = {"blk0_in": toks[-1], "blk0_out": toks[0], "blkL_out": toks[depth - 1]}
+        for k, s_ in ((4, ph), (3, 2 * ph), (2, 4 * ph), (1, 8 * ph)):
+            got[f"path{k}"] = rt.hbuf(f"path{k}", (B * s_ * s_, F)).float().cpu()
+        got["oc1"] = rt.fbuf("out1_f32", (B * 64 * ph * ph, F // 2)).cpu()
+        for k, v in got.items():
+            ref = g[f"{k}_samp_{t}"]
+            err = rel_l2(v.reshape(-1)[sample_idx(v.numel(), len(ref))], ref)
+            st, rs = stats(v), g[f"{k}_stats_{t}"]
+            print(f"[{name}] frame {t} stage {k} {tuple(v.shape)}: samples rel-L2 {err:.2e}, mean {st[0]:.5f} / {rs[0]:.5f}, std {st[1]:.5f} / {rs[1]:.5f}")
+            assert err < TOL and abs(st[1] - rs[1]) <= 1e-3 * rs[1] and abs(st[0] - rs[0]) <= 1e-3 * rs[1], (k, t, err, st, rs)
+    e["enc"].probe = None
 
 
 def _lanes_against_single_lane_and_fixture(name, enc, B, monkeypatch):
@@ -214,12 +252,24 @@ def test_infer_video_depth_windows_and_stitch():
     assert np.allclose(d, host, rtol=2e-5, atol=1e-6), float(np.abs(d - host).max())
 
 
-def test_infer_image_shape():
+def test_image2tensor_and_infer_image_against_oracle():
+    """a1 + a12 (depth_anything_v2.py:57-92): BGR u8 image -> cubic resize to the 14-multiple lower bound -> normalise ->
+    forward -> bilinear back to the image size, against the oracle's restatement of the same pipeline (its cubic resize
+    restates cv2's published algorithm; cross-checked against torch's bicubic in tests/test_host.py)."""
+    from oracle import ref_cpu as O
     from vdn import synth
     model = _product("A", "vits")
-    img = synth.frames_u8(1234, 1, 240, 240)[0][:, :, ::-1]
-    d = model.infer_image(np.ascontiguousarray(img), input_size=266)
-    assert d.shape == (240, 240) and np.isfinite(d).all()
+    img = np.ascontiguousarray(synth.frames_u8(1234, 1, 240, 240)[0][:, :, ::-1])
+    x, (h, w) = model.image2tensor(img, input_size=266)
+    xr, (hr, wr) = O.image2tensor(img, 266)
+    assert (h, w) == (hr, wr) == (240, 240) and tuple(x.shape) == tuple(xr.shape) == (1, 3, 266, 266)
+    assert float((x.cpu() - xr).abs().max()) < 5e-6
+    d = model.infer_image(img, input_size=266)
+    with torch.no_grad():
+        ref = O.infer_image(synth_sd("A", "vits"), img, O.MemoryState(6), "vits", 266)
+    e = rel_l2(d, ref)
+    print(f"[infer_image] 240x240 -> 266 -> 240: rel-L2 vs oracle {e:.2e}")
+    assert d.shape == (240, 240) and np.isfinite(d).all() and e < TOL
 
 
 @pytest.mark.parametrize("precision,limit", [("f16", 3e-3), ("bf16", 3e-2)])

@@ -89,7 +89,7 @@ def test_gemm_argument_validation_without_gpu():
     assert _abi.lib.vdn_gemm(ctypes.byref(d), None) == -2
 
 
-@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitl"), ("B", "vits"), ("B", "vitl")])
+@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitb"), ("A", "vitl"), ("B", "vits"), ("B", "vitl")])
 def test_state_dict_schema_matches_reference(which, enc):
     """Drop-in contract: same parameter/buffer keys and shapes as the reference classes."""
     import vdn
@@ -134,3 +134,23 @@ def test_rope_table_and_pack_geometry():
     assert L.vdn_pack_rows(_abi.PACK_GEGLU, 48, 64, 0) < 0 and L.vdn_pack_rows(_abi.PACK_ROPE, 100, 64, 0) < 0  # bad row counts
     assert L.vdn_pack_weight(_abi.F16, 99, None, 1, 1, 0, None, None, 64, None) == -1
     assert L.vdn_gemm_workspace_bytes(None) == 0 and L.vdn_groupnorm_workspace_bytes(4, 32, 16) == 4 * 16 * 32 * 2 * 4
+
+
+def test_oracle_cubic_resize_matches_torch_bicubic():
+    """oracle.resize_cubic restates cv2.INTER_CUBIC (absent here: parity unpinned against cv2 itself); torch's bicubic is an
+    independent implementation of the same A = -0.75 half-pixel kernel with replicated borders: up- and down-scaling agree."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import ref_cpu as O
+    img = np.random.default_rng(0).random((120, 100, 3))
+    for nw, nh in [(140, 168), (266, 266), (56, 70)]:
+        a = O.resize_cubic(img, nw, nh)
+        b = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(nh, nw), mode="bicubic", align_corners=False)[0]
+        assert a.shape == (nh, nw, 3) and np.abs(a - b.permute(1, 2, 0).numpy()).max() < 1e-12
+    raw = (img * 255).astype(np.uint8)
+    x, (h, w) = O.image2tensor(raw, 140)
+    assert (h, w) == (120, 100) and tuple(x.shape) == (1, 3, 168, 140) and x.dtype == torch.float32
+    same = np.zeros((28, 28, 3), np.uint8) + np.array([10, 20, 30], np.uint8)          # constant image: BGR -> RGB order, mean/std
+    x, _ = O.image2tensor(same, 28)
+    want = (np.array([30, 20, 10]) / 255.0 - np.array([0.485, 0.456, 0.406])) / np.array([0.229, 0.224, 0.225])
+    assert np.allclose(x[0].mean((1, 2)).numpy(), want, atol=1e-6)

@@ -31,6 +31,12 @@ def _run_A(name, enc, check_steps=None):
                     assert rel_l2(pt.reshape(-1)[idx], g[f"tap{i}_samp_{t}"]) < TOL
                 mf = mem.items[-1]["memory_feature"]
                 assert rel_l2(mf.reshape(-1)[sample_idx(mf.numel())], g[f"memfeat_samp_{t}"]) < TOL
+                if f"blk0_in_samp_{t}" in g.files:  # stage fixtures G2 / G4 (forward hooks on the reference), NHWC samples
+                    st = {"blk0_in": tr["tokens0"], "blk0_out": tr["block0"]}
+                    st.update({f"path{k}": tr[f"path_{k}"].permute(0, 2, 3, 1) for k in (4, 3, 2, 1)})
+                    for k, v in st.items():
+                        ref = g[f"{k}_samp_{t}"]
+                        assert rel_l2(v.reshape(-1)[sample_idx(v.numel(), len(ref))], ref) < TOL, (name, t, k)
 
 
 def test_oracle_A_vits_stream_fills_and_evicts():
@@ -41,6 +47,11 @@ def test_oracle_A_vits_stream_fills_and_evicts():
 def test_oracle_A_vits_batch2_nonstandard_grid():
     # 266x266 (19x19 grid): bicubic pos-embed path (dinov2.py:179-210), batch of 2 streams
     _run_A("A_vits_b2_266", "vits")
+
+
+def test_oracle_A_vitb_and_stage_fixtures():
+    _run_A("A_vitb_266", "vitb")
+    _run_A("G_vits_392", "vits")
 
 
 def _run_B(name, enc):

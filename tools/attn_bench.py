@@ -14,7 +14,13 @@ for name, nq, nk in (("encoder", 1370, 1370), ("mem_self", 1369, 1369), ("mem_cr
     k = rt.to_half(torch.randn(B * H, kp, 64, device="cuda"))
     v = rt.to_half(torch.randn(B * H, 64, kp, device="cuda"))
     o = rt.hbuf("o" + name, (B * nq, H * 64))
-    run = lambda: rt.flash_attn(q, k, v, o, B, H, nq, qp, nk, kp, 0.125)
+
+    def planes8(t):  # the 8-bit planes the projection epilogue writes (score cross terms on the e5m2 MFMA: the shipped path)
+        return torch.cat([t.float().to(torch.float8_e5m2).view(torch.uint8),
+                          (t.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)], dim=-1).contiguous()
+
+    kw = dict(q8=planes8(q), k8=planes8(k)) if split and "--no-qk8" not in sys.argv else {}
+    run = lambda: rt.flash_attn(q, k, v, o, B, H, nq, qp, nk, kp, 0.125, **kw)
     for _ in range(3): run()
     torch.cuda.synchronize()
     ts = []

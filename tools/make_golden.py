@@ -107,7 +107,23 @@ class PreRelu:
         self.h = conv.register_forward_hook(lambda m, i, o: self.val.append(o.detach().clone()))
 
 
-def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str):
+class StageHooks:
+    """SURVEY.md §8c fixtures G2 (one full ViT block, in and out) and G4 (DPT path_4..path_1 and output_conv1) from
+    forward hooks on the imported reference. Feature maps are sampled in NHWC order (the product's layout)."""
+
+    def __init__(self, model):
+        self.v = {}
+        blk = model.pretrained.blocks
+        blk[0].register_forward_hook(lambda m, i, o: self.v.update(blk0_in=i[0].detach().clone(), blk0_out=o.detach().clone()))
+        blk[len(blk) - 1].register_forward_hook(lambda m, i, o: self.v.update(blkL_out=o.detach().clone()))
+        sc = model.depth_head.scratch
+        for k in (4, 3, 2, 1):
+            getattr(sc, f"refinenet{k}").register_forward_hook(
+                lambda m, i, o, k=k: self.v.update({f"path{k}": o.detach().permute(0, 2, 3, 1).contiguous()}))
+        sc.output_conv1.register_forward_hook(lambda m, i, o: self.v.update(oc1=o.detach().permute(0, 2, 3, 1).contiguous()))
+
+
+def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str, stages: bool = False):
     from depth_anything_v2.depth_anything_v2 import DepthAnythingV2
     from oracle import ref_cpu as O
     cfg = O.MODEL_CONFIGS[enc]
@@ -119,6 +135,7 @@ def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, na
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
     x_all = make_inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
     hook = PreRelu(model.depth_head.scratch.output_conv2[2])
+    sh = StageHooks(model) if stages else None
     mem = O.MemoryState(6)
     out = {"meta": np.array([B, steps, H, W, sub, SEED])}
     worst = 0.0
@@ -137,6 +154,16 @@ def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, na
         e3 = relerr(mem.items[-1]["memory_feature"], mf_ref)
         e4 = relerr(mem.items[-1]["memory_pos_enc"], model.memory_block.memory_bank.get_memory()[-1]["memory_pos_enc"])
         worst = max(worst, e, e2, e3, e4)
+        if sh is not None and t in keep:
+            mine_st = {"blk0_in": tr["tokens0"], "blk0_out": tr["block0"]}
+            mine_st.update({f"path{k}": tr[f"path_{k}"].permute(0, 2, 3, 1) for k in (4, 3, 2, 1)})
+            for k, v in sh.v.items():
+                out[f"{k}_stats_{t}"] = stats(v)
+                out[f"{k}_samp_{t}"] = samples(v, 1024)[1]
+                if k in mine_st:
+                    es = relerr(mine_st[k], v)
+                    worst = max(worst, es)
+                    print(f"[A {name}] step {t} stage {k} {tuple(v.shape)} oracle rel err {es:.2e}")
         print(f"[A {name}] step {t} S={min(t, 6)} ref {time.time() - t0:.1f}s pre-ReLU mean {pre.mean():.4f} std {pre.std():.4f} "
               f"frac>0 {(pre > 0).float().mean():.3f} | oracle rel err pre {e:.2e} post {e2:.2e} memfeat {e3:.2e} mempos {e4:.2e}")
         if t in keep:
@@ -380,6 +407,9 @@ JOBS = {
     "B_vits_518": lambda: gen_B("vits", 518, 518, 32, [0, 13, 31], 2, "B_vits_518"),
     "B_vits_392x518": lambda: gen_B("vits", 392, 518, 8, [0, 7], 2, "B_vits_392x518"),
     "S_vits_266": lambda: gen_stream("vits", 266, 266, 14, [0, 1, 11, 13], "S_vits_266"),
+    # ViT-B (never tested before) + the stage fixtures G2 / G4 of SURVEY.md §8c
+    "A_vitb_266": lambda: gen_A("vitb", 266, 266, 1, 3, [0, 1, 2], 1, "A_vitb_266", stages=True),
+    "G_vits_392": lambda: gen_A("vits", 392, 392, 1, 2, [0, 1], 2, "G_vits_392", stages=True),
     # BASELINE configs[1]: ViT-L stream through every memory depth S = 0..6 and one eviction
     "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 8, [0, 1, 6, 7], 4, "A_vitl_518"),
     "B_vitl_518": lambda: gen_B("vitl", 518, 518, 4, [0, 3], 4, "B_vitl_518"),

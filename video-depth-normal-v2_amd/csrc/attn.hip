@@ -58,11 +58,20 @@ __device__ __forceinline__ void for_each_slot(F& f) {
   for_each_slot_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-#define GLDS16(src, dst)                                                                  \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
-                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// Timing ablations for tools/attn_ablate.sh variant builds only (results are wrong with any bit set; the shipped
+// library is built without the macro): 1 no LDS-DMA in the loop, 2 no workgroup barrier, 4 no softmax VALU, 8 no MFMA, 32 one workgroup per CU
+// (96 KB of LDS requested: one wave per SIMD).
+#ifndef VDN_ATTN_ABL
+#define VDN_ATTN_ABL 0
+#endif
+// Schedule switches of the hand-placed stream (A/B builds: tools/attn_ablate.sh): 1 row sums pinned to their slot,
+// 2 exp -> convert decoupled by one piece, 4 QK order fp16 x4 then the two 8-bit MFMAs, 8 fragments read two triples
+// ahead, 16 LDS-DMA pieces spread over the VALU-only slots.
+#ifndef VDN_ATTN_OPT
+#define VDN_ATTN_OPT 0
+#endif
 
 template <int DT, bool SPLIT, bool PV2, bool QK8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_kernel(const typename Half<DT>::T* __restrict__ Q,
@@ -114,41 +123,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
-  // ---- staging: 8 pieces (1 KiB = 8 rows) per tile and operand, 2 per wave
-  // wave-uniform tile base (SGPR pair) + loop-invariant 32-bit lane offsets: no per-tile VALU address math
+  // ---- staging: 8 pieces (1 KiB = 8 rows) per tile and operand, 2 per wave, as `buffer_load_dwordx4 ... offen lds`:
+  // the (batch, head)'s plane is a buffer resource (4 SGPRs, hardware range check), the lane's place in a piece a
+  // loop-invariant 32-bit VGPR offset and the tile a SCALAR offset — no vector address arithmetic per tile (the flat
+  // global_load_lds form cost 16 v_lshl_add_u64 per tile and 16 VGPRs of per-lane 64-bit pointers).
   const int lr = lane >> 3;
-  const T* Kb = K + (size_t)bh * nk_pad * 64;
-  const T* Vb = Vt + (size_t)bh * 64 * nk_pad;
-  const ptrdiff_t kl_delta = SPLIT ? (const char*)Kl - (const char*)K : 0;
-  const ptrdiff_t vl_delta = SPLIT ? (const char*)Vtl - (const char*)Vt : 0;
-  unsigned koff[2], voff[2];
+  const unsigned k_bytes = (unsigned)nk_pad * 64 * sizeof(T);  // one plane of one (batch, head): K rows, V^T rows, K8 rows
+  const auto rsrc = [&](const void* base, size_t off) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + off), 0, (int)k_bytes, 0x00020000);
+  };
+  const size_t plane_off = (size_t)bh * k_bytes;
+  const __amdgpu_buffer_rsrc_t rK = rsrc(K, plane_off), rV = rsrc(Vt, plane_off);
+  const __amdgpu_buffer_rsrc_t rKl = rsrc(QK8 ? (const void*)K8 : (const void*)(SPLIT ? Kl : K), plane_off);
+  const __amdgpu_buffer_rsrc_t rVl = rsrc(SPLIT ? Vtl : Vt, plane_off);
+  int koff[2], voff[2];  // byte offsets
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wave + 4 * i) * 8 + lr;
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    koff[i] = (unsigned)(row * 64 + c * 8);
-    voff[i] = (unsigned)(row * nk_pad + c * 8);
+    koff[i] = (row * 64 + c * 8) * (int)sizeof(T);
+    voff[i] = (row * nk_pad + c * 8) * (int)sizeof(T);
   }
+#define BLDS16(rs, voffset, soffset, dst) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 16, voffset, soffset, 0, 0)
+  // piece i (0, 1) of a tile of K (hi plane; second plane = K_lo rows or the 8-bit rows: both 128 B per key) / of V^T
+  auto stage_k_piece = [&](int buf, int t, int i, bool second) {
+    char* sK = smem + buf * NT * TILE + (second ? 2 * TILE : 0);
+    BLDS16(second ? rKl : rK, koff[i], t * (64 * 64 * (int)sizeof(T)), sK + (wave + 4 * i) * 1024);
+  };
+  auto stage_v_piece = [&](int buf, int t, int i, bool second) {
+    char* sV = smem + buf * NT * TILE + TILE + (second ? 2 * TILE : 0);
+    BLDS16(second ? rVl : rV, voff[i], t * (64 * (int)sizeof(T)), sV + (wave + 4 * i) * 1024);
+  };
   auto stage_k = [&](int buf, int t) {
-    char* sK = smem + buf * NT * TILE;
-    const T* kt = Kb + (size_t)t * 4096;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pc = wave + 4 * i;
-      GLDS16(kt + koff[i], sK + pc * 1024);
-      if constexpr (QK8)  // the 8-bit tile: 64 keys x (64 B e5m2(K) | 64 B e5m2(K_lo 2^10)) = the same 128-byte rows
-        GLDS16(K8 + ((size_t)bh * nk_pad + (size_t)t * 64) * 128 + koff[i] * 2, sK + 2 * TILE + pc * 1024);
-      else if constexpr (SPLIT) GLDS16((const char*)(kt + koff[i]) + kl_delta, sK + 2 * TILE + pc * 1024);
+      stage_k_piece(buf, t, i, false);
+      if constexpr (SPLIT) stage_k_piece(buf, t, i, true);
     }
   };
   auto stage_v = [&](int buf, int t) {
-    char* sV = smem + buf * NT * TILE + TILE;
-    const T* vt = Vb + (size_t)t * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pc = wave + 4 * i;
-      GLDS16(vt + voff[i], sV + pc * 1024);
-      if constexpr (SPLIT) GLDS16((const char*)(vt + voff[i]) + vl_delta, sV + 2 * TILE + pc * 1024);
+      stage_v_piece(buf, t, i, false);
+      if constexpr (SPLIT) stage_v_piece(buf, t, i, true);
     }
   };
 
@@ -239,9 +257,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto iter = [&](int t, auto has_prev_c, auto has_next_c) {
     constexpr bool HAS_PREV = decltype(has_prev_c)::value, HAS_NEXT = decltype(has_next_c)::value;
     const int cur = t & 1;
-    stage_v(cur, t);
-    if constexpr (HAS_NEXT) {
-      if (t + 2 < nt) stage_k(cur, t + 2);
+    constexpr bool SPREAD = (VDN_ATTN_OPT & 16) && SPLIT;
+    if constexpr (!(VDN_ATTN_ABL & 1) && !SPREAD) {
+      stage_v(cur, t);
+      if constexpr (HAS_NEXT) {
+        if (t + 2 < nt) stage_k(cur, t + 2);
+      }
     }
     if constexpr (!HAS_NEXT) {  // only the last tile can be ragged
       if ((t + 1) * 64 > nk) {
@@ -264,7 +285,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //   P fragment f is read by PV(t-1) in slots 6f..6f+5 and rewritten by softmax(t) in slots >= 7+8f;
     //   S[0] is last read in slot 20 and overwritten by QK(t+1) from slot 24, S[1] read in 36 (softmax piece
     //   first in the slot), overwritten from slot 36's MFMA on.
-    V8 fa[2], fl[2];
+    constexpr bool QK_FIRST = (VDN_ATTN_OPT & 4) && QK8;  // the two 8-bit MFMAs open their key block's chain (slots q = 0, 1 of ks = 0)
+    constexpr int NF = (VDN_ATTN_OPT & 8) ? 3 : 2;        // fragment buffers: a triple's operands are read NF - 1 triples ahead
+    V8 fa[NF], fl[NF];
     i32x8 f8[2];  // QK8: the 8-bit K fragment of triples (kb, ks = 0) [e5m2(K)] and (kb, ks = 1) [remainder plane]
     auto frag = [&](auto jc, V8& a, V8& al) {
       constexpr int j = decltype(jc)::value;
@@ -276,7 +299,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       } else if constexpr (HAS_NEXT) {
         a = *(const V8*)(sKn + k_addr((j - 8) >> 2, (j - 8) & 3));
         if constexpr (QK8) {
-          if constexpr (((j - 8) & 3) < 2) f8[j & 1] = k8_read(sKn, (j - 8) >> 2, (j - 8) & 3);
+          constexpr int ks = (j - 8) & 3;
+          if constexpr (!QK_FIRST && ks < 2) f8[ks] = k8_read(sKn, (j - 8) >> 2, ks);
+          if constexpr (QK_FIRST && ks == 0) { f8[0] = k8_read(sKn, (j - 8) >> 2, 0); f8[1] = k8_read(sKn, (j - 8) >> 2, 1); }
         } else if constexpr (SPLIT) {
           al = *(const V8*)(sKn + 2 * TILE + k_addr((j - 8) >> 2, (j - 8) & 3));
         }
@@ -294,7 +319,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       } else if constexpr (HAS_NEXT) {
         constexpr int kb = (j - 8) >> 2, ks = (j - 8) & 3;
-        if constexpr (ks == 0 && q == 0) {
+        if constexpr (QK_FIRST) {
+          // per 32-key block: 8-bit K8 Q_lo8 (C = 0), 8-bit K_lo8 Q8, then the four fp16 MFMAs (ks = 0 in slot q = 2)
+          if constexpr (ks == 0 && q == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.f;
+            s[kb] = cross_hl(f8[0], z);
+          }
+          if constexpr (ks == 0 && q == 1) s[kb] = cross_lh(f8[1], s[kb]);
+          if constexpr ((ks == 0 && q == 2) || (ks > 0 && q == 0)) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
+        } else if constexpr (ks == 0 && q == 0) {
           f32x16 z;
 #pragma unroll
           for (int i = 0; i < 16; ++i) z[i] = 0.f;
@@ -303,8 +338,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           // 6 MFMAs per 32-key block in its 12 slots: 4 fp16 (q == 0) + the two 8-bit cross terms in the q == 1 slots
           // of ks = 0, 1 (twice as long as a fp16 MFMA: they hide two softmax pieces); the other slots are VALU-only
           if constexpr (q == 0) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
-          if constexpr (q == 1 && ks == 0) s[kb] = cross_hl(f8[j & 1], s[kb]);
-          if constexpr (q == 1 && ks == 1) s[kb] = cross_lh(f8[j & 1], s[kb]);
+          if constexpr (q == 1 && ks == 0) s[kb] = cross_hl(f8[0], s[kb]);
+          if constexpr (q == 1 && ks == 1) s[kb] = cross_lh(f8[1], s[kb]);
         } else {
           if constexpr (q == 0) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
           if constexpr (q == 1) s[kb] = HT::mfma32(a, ql[ks], s[kb]);
@@ -313,6 +348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     };
     float mx = -1e30f, alpha = 1.f, mb = 0.f, ls = 0.f, px0 = 0.f, px1 = 0.f;
+    float pe[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    constexpr bool DECOUPLE = (VDN_ATTN_OPT & 2) && SPLIT && PV2 && DT == VDN_F16;
     bool bump = false;
     auto vstep = [&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -330,6 +367,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);  // == 1 when not bumped
         m_run = m_new;
         mb = -m_new * scale_log2;
+      } else if constexpr (DECOUPLE) {
+        // piece order E0 E1 C0 E2 C1 E3 ... E15 C14 - C15: a convert reads exponentials issued a whole piece earlier
+        // (the transcendental's latency is not waited for in front of the next MFMA)
+        if constexpr (k == 6 || k == 7 || (k >= 9 && k <= 35 && (k & 1))) {
+          constexpr int pi = k < 8 ? k - 6 : (k - 5) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
+          pe[pi & 1][0] = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2, mb));
+          pe[pi & 1][1] = __builtin_amdgcn_exp2f(fmaf(s[kb][i + 1], scale_log2, mb));
+        } else if constexpr (k >= 8 && k <= 38 && !(k & 1)) {
+          constexpr int pi = (k - 8) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
+          const f16x2 pp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(pe[pi & 1][0], pe[pi & 1][1]));
+          pf[kb][i >> 3][i & 7] = pp[0]; pf[kb][i >> 3][(i & 7) + 1] = pp[1];
+          ls = __builtin_amdgcn_fdot2(pp, f16x2{(_Float16)1.f, (_Float16)1.f}, ls, false);
+          if constexpr (VDN_ATTN_OPT & 1) asm volatile("" : "+v"(ls));
+        } else if constexpr (k == 39) {
+          l_run = l_run * alpha + ls;
+        }
       } else if constexpr (k < 38) {
         constexpr int pi = (k - 6) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
         if constexpr (((k - 6) & 1) == 0) {
@@ -340,6 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const f16x2 pp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(px0, px1));
             pf[kb][i >> 3][i & 7] = pp[0]; pf[kb][i >> 3][(i & 7) + 1] = pp[1];
             ls = __builtin_amdgcn_fdot2(pp, f16x2{(_Float16)1.f, (_Float16)1.f}, ls, false);
+            if constexpr (VDN_ATTN_OPT & 1) asm volatile("" : "+v"(ls));  // or LLVM sinks all 16 dot2 behind the last MFMA
           } else {
             const T a0 = (T)px0, a1 = (T)px1;
             pf[kb][i >> 3][i & 7] = a0; pf[kb][i >> 3][(i & 7) + 1] = a1;
@@ -360,14 +414,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         l_run = l_run * alpha + ls;
       }
     };
+    // LDS-DMA pieces of this iteration (V_t: 4, K_{t+2}: 4 per wave) in the slots that carry no MFMA
+    auto dma = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (SPREAD && !(VDN_ATTN_ABL & 1)) {
+        if constexpr (j == 1) stage_v_piece(cur, t, 0, false);
+        if constexpr (j == 4) stage_v_piece(cur, t, 0, true);
+        if constexpr (j == 7) stage_v_piece(cur, t, 1, false);
+        if constexpr (j == 10) stage_v_piece(cur, t, 1, true);
+        // no branch inside the stream (it would split the basic block the slot fences live in): past the end the LAST
+        // tile is fetched again, into the buffer nobody reads any more
+        if constexpr (HAS_NEXT && (j == 13 || j == 16 || j == 19 || j == 22))
+          stage_k_piece(cur, t + 2 < nt ? t + 2 : nt - 1, (j - 13) / 6, ((j - 13) / 3) & 1);
+      }
+    };
     auto slot = [&](auto jc) {
       constexpr int j = decltype(jc)::value, tj = j / 3, q = j % 3;
-      if constexpr (q == 0 && tj + 1 < 16) frag(std::integral_constant<int, tj + 1>{}, fa[(tj + 1) & 1], fl[(tj + 1) & 1]);
-      vstep(jc);
-      mma(std::integral_constant<int, tj>{}, std::integral_constant<int, q>{}, fa[tj & 1], fl[tj & 1]);
+      constexpr int ahead = NF - 1;
+      if constexpr (q == 0 && tj + ahead < 16)
+        frag(std::integral_constant<int, tj + ahead>{}, fa[(tj + ahead) % NF], fl[(tj + ahead) % NF]);
+      dma(jc);
+      if constexpr (!(VDN_ATTN_ABL & 4)) vstep(jc);
+      if constexpr (!(VDN_ATTN_ABL & 8)) mma(std::integral_constant<int, tj>{}, std::integral_constant<int, q>{}, fa[tj % NF], fl[tj % NF]);
       __builtin_amdgcn_sched_barrier(0);
     };
     frag(std::integral_constant<int, 0>{}, fa[0], fl[0]);
+    if constexpr (NF == 3) frag(std::integral_constant<int, 1>{}, fa[1], fl[1]);
     for_each_slot<48>(slot);
 
     // P(t) is only consumed by the next iteration's MFMAs: keep LLVM from sinking its computation there.
@@ -378,7 +450,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
     }
-    stage_barrier();
+    if constexpr (VDN_ATTN_ABL & 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else stage_barrier();
   };
 
   stage_k(0, 0);
@@ -666,7 +739,7 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
   else if (Ql && q8 && k8 && DT == VDN_F16) {
     if constexpr (DT == VDN_F16)
-      hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
+      hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                          (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
   } else if (Ql)
     hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,

@@ -93,6 +93,9 @@ class EncoderEngine:
         f1 = rt.hbuf("enc_fc1", (M, 4 * C))
         heads = dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
         outs, last_f32 = [], None
+        probe = getattr(self, "probe", None)   # tests only: callable(block index, fp32 token stream [M, C]); -1 = input of block 0
+        if probe is not None:
+            probe(-1, tok)
         for i, b in enumerate(self.blocks):
             rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
             rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear")
@@ -101,6 +104,8 @@ class EncoderEngine:
             rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
             rt.gemm(hn, b["wfc1"], M, 4 * C, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
             rt.gemm(f1, b["wfc2"], M, C, 4 * C, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
+            if probe is not None:
+                probe(i, tok)
             if i in self.taps:
                 j = self.taps.index(i)
                 t = tap_out[j] if tap_out is not None else rt.hbuf(f"tap{j}", (Bf * P, C))
