@@ -196,6 +196,11 @@ int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* o
  * within ~1e-6 of fp64 at ~13 % more kernel time). Process-wide; set before launching. VDN_ATTN_PV3=1 = default 3. */
 int vdn_flash_attn_set_pv_products(int n);
 int vdn_flash_attn_get_pv_products(void);
+/* Instruction stream of the attention with 8-bit cross terms (same products, same arithmetic per element): 2 (default) =
+ * generated stream with S and P double-buffered by tile parity and the softmax as a 3-stage pipeline across MFMA gaps;
+ * 1 = the hand-placed 48-slot stream of round 1 (A/B and regression). Process-wide. VDN_ATTN_STREAM=1 = default 1. */
+int vdn_flash_attn_set_stream(int v);
+int vdn_flash_attn_get_stream(void);
 
 /* Temporal attention over <=64 frames per (pixel, head) (32 in the 32-frame windows, 64 in the v5 refiner): qkv half [(b f), D, 3c] packed
  * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)

@@ -263,7 +263,7 @@ def test_image2tensor_and_infer_image_against_oracle():
     x, (h, w) = model.image2tensor(img, input_size=266)
     xr, (hr, wr) = O.image2tensor(img, 266)
     assert (h, w) == (hr, wr) == (240, 240) and tuple(x.shape) == tuple(xr.shape) == (1, 3, 266, 266)
-    assert float((x.cpu() - xr).abs().max()) < 5e-6
+    assert float((x.cpu() - xr).abs().max()) < 5e-5   # fp32 cubic on the device against the float64 restatement, values O(1)
     d = model.infer_image(img, input_size=266)
     with torch.no_grad():
         ref = O.infer_image(synth_sd("A", "vits"), img, O.MemoryState(6), "vits", 266)

@@ -495,10 +495,10 @@ def test_x3_heads_rope_and_flash(rt3):
     close(out.float().reshape(B, P, C), ref, 3e-4)
 
 
-@pytest.mark.parametrize("pv,tol,qk8", [(3, 1e-5, False), (2, 3e-4, False), (2, 3e-4, True)])
+@pytest.mark.parametrize("pv,tol,qk8,stream", [(3, 1e-5, False, 2), (2, 3e-4, False, 2), (2, 3e-4, True, 2), (2, 3e-4, True, 1)])
 @pytest.mark.parametrize("nq,nk,gain", [(150, 200, 1.0), (1370, 1370, 1.0), (37, 64, 1.0), (70, 128, 1.0), (100, 130, 1.0),
-                                        (129, 777, 6.0)])
-def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8):
+                                        (129, 777, 6.0), (40, 8214, 1.0), (300, 321, 3.0)])
+def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
     """1 / 2 / 3 / many key tiles (the software pipeline's prologue, peeled first and last iterations), ragged
     last tile; gain 6 makes row maxima jump by far more than the lazy-rescale threshold between tiles.
     pv = 3: P carried as hi/lo planes, fp32-faithful (1e-5 against fp64). pv = 2 (the default): every softmax weight
@@ -506,10 +506,13 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8):
     independent random V rows (the worst case: nothing in common to cancel) gives ~1e-4; end to end it is invisible
     (tests/test_gpu_e2e.py prints 4e-6..1e-5 either way). qk8: the score cross terms K_hi Q_lo^T + K_lo Q_hi^T on the
     block-scaled e5m2 MFMA from the 8-bit planes (built here as the projection epilogue builds them); its own error
-    (~1e-5 of a logit) disappears under the pv = 2 rounding."""
+    (~1e-5 of a logit) disappears under the pv = 2 rounding. stream: with the 8-bit planes, 2 = flash_attn2_kernel (the default:
+    generated instruction stream, S and P double-buffered by tile parity — 1, 2, 3, 4, 6, 13, 22 and 129 tiles walk every
+    first / even / odd / last instantiation), 1 = the hand-placed 48-slot kernel; same products, so both meet the same bound."""
     from vdn import _abi
     from vdn.runtime import ceil_to
     _abi.lib.vdn_flash_attn_set_pv_products(pv)
+    assert _abi.lib.vdn_flash_attn_set_stream(stream) == 0 and _abi.lib.vdn_flash_attn_get_stream() == stream
     B, H = 1, 2
     q, k, v = rnd(B, H, nq, 64, seed=230, scale=gain), rnd(B, H, nk, 64, seed=231), rnd(B, H, nk, 64, seed=232)
     ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(1, 2).reshape(B, nq, H * 64)
@@ -538,6 +541,7 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8):
             assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
     finally:
         _abi.lib.vdn_flash_attn_set_pv_products(2)
+        _abi.lib.vdn_flash_attn_set_stream(2)
 
 
 @pytest.mark.parametrize("T", [32, 64, 50])

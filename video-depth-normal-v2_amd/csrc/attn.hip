@@ -61,7 +61,7 @@ __device__ __forceinline__ void for_each_slot(F& f) {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // Timing ablations for tools/attn_ablate.sh variant builds only (results are wrong with any bit set; the shipped
-// library is built without the macro): 1 no LDS-DMA in the loop, 2 no workgroup barrier, 4 no softmax VALU, 8 no MFMA, 32 one workgroup per CU
+// library is built without the macro): 1 no LDS-DMA in the loop, 2 no workgroup barrier, 4 no softmax VALU, 8 no MFMA, 16 no fragment reads from LDS, 32 one workgroup per CU
 // (96 KB of LDS requested: one wave per SIMD).
 #ifndef VDN_ATTN_ABL
 #define VDN_ATTN_ABL 0
@@ -291,7 +291,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     i32x8 f8[2];  // QK8: the 8-bit K fragment of triples (kb, ks = 0) [e5m2(K)] and (kb, ks = 1) [remainder plane]
     auto frag = [&](auto jc, V8& a, V8& al) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (j < 8) {
+      if constexpr (VDN_ATTN_ABL & 16) {
+        asm volatile("" : "+v"(a), "+v"(al));  // timing ablation: no fragment reads (operands stay what they were)
+      } else if constexpr (j < 8) {
         if constexpr (HAS_PREV) {
           a = *(const V8*)(sVp + v_addr(j & 1, j >> 1));
           if constexpr (SPLIT) al = *(const V8*)(sVp + 2 * TILE + v_addr(j & 1, j >> 1));
@@ -498,6 +500,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
   }
 }
+
+#include "attn2_kernel.hpp"
 
 template <int DT, bool SPLIT, int NB /*32-frame blocks: sequences of up to 32 NB frames*/>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<DT>::T* __restrict__ qkv,
@@ -726,6 +730,13 @@ int& pv_products() {
   return v;
 }
 
+// process-wide: instruction stream of the default-mode attention: 2 = flash_attn2_kernel (generated stream, S and P double
+// buffered), 1 = flash_attn_kernel<QK8> (hand-placed 48-slot stream). VDN_ATTN_STREAM=1 selects the older one at the first use.
+int& attn_stream() {
+  static int v = [] { const char* e = getenv("VDN_ATTN_STREAM"); return (e && atoi(e) == 1) ? 1 : 2; }();
+  return v;
+}
+
 template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
                  void* outl, const void* Q8, const void* K8, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
@@ -738,9 +749,14 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
     hipLaunchKernelGGL((flash_attn_kernel<DT, true, false, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
   else if (Ql && q8 && k8 && DT == VDN_F16) {
-    if constexpr (DT == VDN_F16)
+    if constexpr (DT == VDN_F16) {
+      if (attn_stream() == 2)
+        hipLaunchKernelGGL(flash_attn2_kernel, grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
+                           (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+      else
       hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                          (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+    }
   } else if (Ql)
     hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
@@ -778,6 +794,12 @@ extern "C" int vdn_flash_attn_set_pv_products(int n) {
   return VDN_OK;
 }
 extern "C" int vdn_flash_attn_get_pv_products(void) { return pv_products(); }
+extern "C" int vdn_flash_attn_set_stream(int v) {
+  if (v != 1 && v != 2) return VDN_EINVAL;
+  attn_stream() = v;
+  return VDN_OK;
+}
+extern "C" int vdn_flash_attn_get_stream(void) { return attn_stream(); }
 
 extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                               const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, int B, int H,

@@ -75,6 +75,8 @@ EXPORTS = {
                                  C.c_int, C.c_float, vp]),
     "vdn_flash_attn_set_pv_products": (C.c_int, [C.c_int]),
     "vdn_flash_attn_get_pv_products": (C.c_int, []),
+    "vdn_flash_attn_set_stream": (C.c_int, [C.c_int]),
+    "vdn_flash_attn_get_stream": (C.c_int, []),
     "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp,
                                 C.c_int, vp]),

@@ -25,7 +25,8 @@ def _newer(src_list, target):
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_kernels.hpp"), os.path.join(os.path.dirname(PKG), "include", "vdn.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hpp", ".inc"))]
+    hdrs.append(os.path.join(os.path.dirname(PKG), "include", "vdn.h"))
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
