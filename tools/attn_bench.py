@@ -31,4 +31,7 @@ for name, nq, nk in (("encoder", 1370, 1370), ("mem_self", 1369, 1369), ("mem_cr
         s.record(); run(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
     ts.sort(); med = ts[len(ts) // 2]
     fl = 4.0 * B * H * nq * nk * 64
+    if os.environ.get("VDN_ATTN_STAMPS"):  # timing build (VDN_ATTN_ABL & 64): cycle sums of one wave, 4 stream quarters + tail
+        st = o.hi.reshape(-1)[:20].view(torch.int64).cpu().tolist()
+        print("   stamps (cycles per tile: 4 quarters of the stream, then bump/barrier tail):", [round(v / ((nk + 63) // 64), 1) for v in st], flush=True)
     print(f"{name:14s} nq={nq} nk={nk}  {med*1e3:8.1f} us  alg {fl/med/1e9:7.1f} TF/s  executed {(3 if split else 1)*fl/med/1e9:7.1f} TF/s", flush=True)

@@ -66,12 +66,6 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 #ifndef VDN_ATTN_ABL
 #define VDN_ATTN_ABL 0
 #endif
-// Schedule switches of the hand-placed stream (A/B builds: tools/attn_ablate.sh): 1 row sums pinned to their slot,
-// 2 exp -> convert decoupled by one piece, 4 QK order fp16 x4 then the two 8-bit MFMAs, 8 fragments read two triples
-// ahead, 16 LDS-DMA pieces spread over the VALU-only slots.
-#ifndef VDN_ATTN_OPT
-#define VDN_ATTN_OPT 0
-#endif
 
 template <int DT, bool SPLIT, bool PV2, bool QK8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn_kernel(const typename Half<DT>::T* __restrict__ Q,
@@ -257,8 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto iter = [&](int t, auto has_prev_c, auto has_next_c) {
     constexpr bool HAS_PREV = decltype(has_prev_c)::value, HAS_NEXT = decltype(has_next_c)::value;
     const int cur = t & 1;
-    constexpr bool SPREAD = (VDN_ATTN_OPT & 16) && SPLIT;
-    if constexpr (!(VDN_ATTN_ABL & 1) && !SPREAD) {
+    if constexpr (!(VDN_ATTN_ABL & 1)) {
       stage_v(cur, t);
       if constexpr (HAS_NEXT) {
         if (t + 2 < nt) stage_k(cur, t + 2);
@@ -285,9 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //   P fragment f is read by PV(t-1) in slots 6f..6f+5 and rewritten by softmax(t) in slots >= 7+8f;
     //   S[0] is last read in slot 20 and overwritten by QK(t+1) from slot 24, S[1] read in 36 (softmax piece
     //   first in the slot), overwritten from slot 36's MFMA on.
-    constexpr bool QK_FIRST = (VDN_ATTN_OPT & 4) && QK8;  // the two 8-bit MFMAs open their key block's chain (slots q = 0, 1 of ks = 0)
-    constexpr int NF = (VDN_ATTN_OPT & 8) ? 3 : 2;        // fragment buffers: a triple's operands are read NF - 1 triples ahead
-    V8 fa[NF], fl[NF];
+    V8 fa[2], fl[2];
     i32x8 f8[2];  // QK8: the 8-bit K fragment of triples (kb, ks = 0) [e5m2(K)] and (kb, ks = 1) [remainder plane]
     auto frag = [&](auto jc, V8& a, V8& al) {
       constexpr int j = decltype(jc)::value;
@@ -302,8 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         a = *(const V8*)(sKn + k_addr((j - 8) >> 2, (j - 8) & 3));
         if constexpr (QK8) {
           constexpr int ks = (j - 8) & 3;
-          if constexpr (!QK_FIRST && ks < 2) f8[ks] = k8_read(sKn, (j - 8) >> 2, ks);
-          if constexpr (QK_FIRST && ks == 0) { f8[0] = k8_read(sKn, (j - 8) >> 2, 0); f8[1] = k8_read(sKn, (j - 8) >> 2, 1); }
+          if constexpr (ks < 2) f8[ks] = k8_read(sKn, (j - 8) >> 2, ks);
         } else if constexpr (SPLIT) {
           al = *(const V8*)(sKn + 2 * TILE + k_addr((j - 8) >> 2, (j - 8) & 3));
         }
@@ -321,17 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       } else if constexpr (HAS_NEXT) {
         constexpr int kb = (j - 8) >> 2, ks = (j - 8) & 3;
-        if constexpr (QK_FIRST) {
-          // per 32-key block: 8-bit K8 Q_lo8 (C = 0), 8-bit K_lo8 Q8, then the four fp16 MFMAs (ks = 0 in slot q = 2)
-          if constexpr (ks == 0 && q == 0) {
-            f32x16 z;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            s[kb] = cross_hl(f8[0], z);
-          }
-          if constexpr (ks == 0 && q == 1) s[kb] = cross_lh(f8[1], s[kb]);
-          if constexpr ((ks == 0 && q == 2) || (ks > 0 && q == 0)) s[kb] = HT::mfma32(a, qf[ks], s[kb]);
-        } else if constexpr (ks == 0 && q == 0) {
+        if constexpr (ks == 0 && q == 0) {
           f32x16 z;
 #pragma unroll
           for (int i = 0; i < 16; ++i) z[i] = 0.f;
@@ -350,8 +330,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     };
     float mx = -1e30f, alpha = 1.f, mb = 0.f, ls = 0.f, px0 = 0.f, px1 = 0.f;
-    float pe[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    constexpr bool DECOUPLE = (VDN_ATTN_OPT & 2) && SPLIT && PV2 && DT == VDN_F16;
     bool bump = false;
     auto vstep = [&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -369,22 +347,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);  // == 1 when not bumped
         m_run = m_new;
         mb = -m_new * scale_log2;
-      } else if constexpr (DECOUPLE) {
-        // piece order E0 E1 C0 E2 C1 E3 ... E15 C14 - C15: a convert reads exponentials issued a whole piece earlier
-        // (the transcendental's latency is not waited for in front of the next MFMA)
-        if constexpr (k == 6 || k == 7 || (k >= 9 && k <= 35 && (k & 1))) {
-          constexpr int pi = k < 8 ? k - 6 : (k - 5) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
-          pe[pi & 1][0] = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2, mb));
-          pe[pi & 1][1] = __builtin_amdgcn_exp2f(fmaf(s[kb][i + 1], scale_log2, mb));
-        } else if constexpr (k >= 8 && k <= 38 && !(k & 1)) {
-          constexpr int pi = (k - 8) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
-          const f16x2 pp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(pe[pi & 1][0], pe[pi & 1][1]));
-          pf[kb][i >> 3][i & 7] = pp[0]; pf[kb][i >> 3][(i & 7) + 1] = pp[1];
-          ls = __builtin_amdgcn_fdot2(pp, f16x2{(_Float16)1.f, (_Float16)1.f}, ls, false);
-          if constexpr (VDN_ATTN_OPT & 1) asm volatile("" : "+v"(ls));
-        } else if constexpr (k == 39) {
-          l_run = l_run * alpha + ls;
-        }
       } else if constexpr (k < 38) {
         constexpr int pi = (k - 6) >> 1, kb = pi >> 3, i = (pi & 7) * 2;
         if constexpr (((k - 6) & 1) == 0) {
@@ -395,7 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const f16x2 pp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(px0, px1));
             pf[kb][i >> 3][i & 7] = pp[0]; pf[kb][i >> 3][(i & 7) + 1] = pp[1];
             ls = __builtin_amdgcn_fdot2(pp, f16x2{(_Float16)1.f, (_Float16)1.f}, ls, false);
-            if constexpr (VDN_ATTN_OPT & 1) asm volatile("" : "+v"(ls));  // or LLVM sinks all 16 dot2 behind the last MFMA
+            asm volatile("" : "+v"(ls));  // or LLVM sinks all 16 dot2 behind the last MFMA of the iteration
           } else {
             const T a0 = (T)px0, a1 = (T)px1;
             pf[kb][i >> 3][i & 7] = a0; pf[kb][i >> 3][(i & 7) + 1] = a1;
@@ -416,32 +378,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         l_run = l_run * alpha + ls;
       }
     };
-    // LDS-DMA pieces of this iteration (V_t: 4, K_{t+2}: 4 per wave) in the slots that carry no MFMA
-    auto dma = [&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if constexpr (SPREAD && !(VDN_ATTN_ABL & 1)) {
-        if constexpr (j == 1) stage_v_piece(cur, t, 0, false);
-        if constexpr (j == 4) stage_v_piece(cur, t, 0, true);
-        if constexpr (j == 7) stage_v_piece(cur, t, 1, false);
-        if constexpr (j == 10) stage_v_piece(cur, t, 1, true);
-        // no branch inside the stream (it would split the basic block the slot fences live in): past the end the LAST
-        // tile is fetched again, into the buffer nobody reads any more
-        if constexpr (HAS_NEXT && (j == 13 || j == 16 || j == 19 || j == 22))
-          stage_k_piece(cur, t + 2 < nt ? t + 2 : nt - 1, (j - 13) / 6, ((j - 13) / 3) & 1);
-      }
-    };
     auto slot = [&](auto jc) {
       constexpr int j = decltype(jc)::value, tj = j / 3, q = j % 3;
-      constexpr int ahead = NF - 1;
-      if constexpr (q == 0 && tj + ahead < 16)
-        frag(std::integral_constant<int, tj + ahead>{}, fa[(tj + ahead) % NF], fl[(tj + ahead) % NF]);
-      dma(jc);
+      if constexpr (q == 0 && tj + 1 < 16) frag(std::integral_constant<int, tj + 1>{}, fa[(tj + 1) & 1], fl[(tj + 1) & 1]);
       if constexpr (!(VDN_ATTN_ABL & 4)) vstep(jc);
-      if constexpr (!(VDN_ATTN_ABL & 8)) mma(std::integral_constant<int, tj>{}, std::integral_constant<int, q>{}, fa[tj % NF], fl[tj % NF]);
+      if constexpr (!(VDN_ATTN_ABL & 8)) mma(std::integral_constant<int, tj>{}, std::integral_constant<int, q>{}, fa[tj & 1], fl[tj & 1]);
       __builtin_amdgcn_sched_barrier(0);
     };
     frag(std::integral_constant<int, 0>{}, fa[0], fl[0]);
-    if constexpr (NF == 3) frag(std::integral_constant<int, 1>{}, fa[1], fl[1]);
     for_each_slot<48>(slot);
 
     // P(t) is only consumed by the next iteration's MFMAs: keep LLVM from sinking its computation there.

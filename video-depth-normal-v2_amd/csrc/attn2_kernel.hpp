@@ -104,6 +104,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nt = (nk + 63) >> 6;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+#if VDN_ATTN_ABL & 64
+  unsigned long long stamp_sum[5] = {0, 0, 0, 0, 0}, stamp_last = 0;
+#endif
 #define A2_IC(n) std::integral_constant<int, n> {}
   // pin a value to this point of the stream (LLVM otherwise sinks work whose result is only used next iteration)
 #define A2_PIN(x) asm volatile("" : "+v"(x))
@@ -239,7 +242,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define A2_DMA(i) dma(A2_IC(i));
 #endif
 #define A2_FENCE() __builtin_amdgcn_sched_barrier(0);
+#if VDN_ATTN_ABL & 64  // timing build: cycles of the four quarters of the stream (and of the iteration's tail) summed per wave
+#define A2_STAMP(i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (i > 0) stamp_sum[i - 1] += now - stamp_last; stamp_last = now; }
+#include "attn2_stream_stamps.inc"
+#undef A2_STAMP
+#else
 #include "attn2_stream.inc"
+#endif
 #undef A2_LDV
 #undef A2_LDK
 #undef A2_LDK8
@@ -265,6 +274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if constexpr (VDN_ATTN_ABL & 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else stage_barrier();
+#if VDN_ATTN_ABL & 64
+    { const unsigned long long now = __builtin_amdgcn_s_memtime(); stamp_sum[4] += now - stamp_last; stamp_last = now; }
+#endif
   };
 
   // ---- prologue: K_0 (and K_1) in flight, S(0) from buffer 0
@@ -314,6 +326,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else pv_last(pf[0]);
   }
 
+#if VDN_ATTN_ABL & 64
+  if (blockIdx.x == 300 && tid == 0)  // one wave of a mid-grid workgroup reports (the output is garbage in this build anyway)
+    for (int i = 0; i < 5; ++i) ((unsigned long long*)out)[i] = stamp_sum[i];
+#endif
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
