@@ -339,8 +339,13 @@ def main():
                    "lanes": lanes, "precision": prec_name, "ranks": n_gpus,
                    "backend": ("gloo (stub rehearsal on CPU)" if a.stub else "gloo (ranks share one GPU: rehearsal)" if a.shared_gpu and dist is not None
                                else ("nccl (RCCL)" if dist is not None else "none")),
-                   "precision_note": "f16x3 = fp16 hi/lo planes, 3 MFMA products per term (fp32-faithful, parity <=1e-3)"},
+                   "precision_note": "f16x3 = fp16 hi/lo planes, 3 MFMA products per term (fp32-faithful, parity <=1e-3); attention: "
+                                     "8-bit score cross terms, P V products per term = attention_pv_products (1: V as one fp16 plane "
+                                     "rounded to nearest; measured 2e-5..9e-5 end to end against the 1e-3 tolerance)"},
     }
+    if not a.stub:
+        from vdn import _abi
+        out["config"]["attention_pv_products"] = int(_abi.lib.vdn_flash_attn_get_pv_products())
     if strong:
         jobs = plan_schedule(n_windows, n_gpus)
         out["config"]["schedule"] = {"windows": n_windows, "whole_window_jobs": sum(1 for j in jobs if j[2] == 1),

@@ -190,10 +190,15 @@ int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, cons
 int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                    const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, int B, int H, int nq,
                    int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
-/* Split-plane mode only: MFMA products per P V term. 2 (default): the softmax weights, born in registers, are
+/* Split-plane mode only: MFMA products per P V term. 2: the softmax weights, born in registers, are
  * rounded once to 16 bits and the row sum uses the same rounded weights (O = sum p~ V / sum p~, V at 21 bits): each
  * weight is off by <= 2^-11 relative, common factors cancel. 3: P is split into hi / lo planes too (every output
- * within ~1e-6 of fp64 at ~13 % more kernel time). Process-wide; set before launching. VDN_ATTN_PV3=1 = default 3. */
+ * within ~1e-6 of fp64 at ~13 % more kernel time). 1 (the DEFAULT; fp16 planes with Q8 / K8 only, else treated as 2): V
+ * enters as its hi plane alone, which the producer rounds to nearest (vdn_gemm writes the hi plane of TRANSPOSED head splits that way; lo = remainder): every output
+ * element is a convex combination of fp16-rounded V values, i.e. within 2^-12 relative of the 2-product result at worst;
+ * 2e-5..9e-5 end to end on the fixtures against the 1e-3 tolerance (2: 7e-6..2e-5), 14-17 % less kernel time.
+ * Process-wide; set it before the first forward (a memory bank keeps the V planes its producer wrote).
+ * VDN_ATTN_PV = 1 | 2 | 3 sets the default. */
 int vdn_flash_attn_set_pv_products(int n);
 int vdn_flash_attn_get_pv_products(void);
 /* Instruction stream of the attention with 8-bit cross terms (same products, same arithmetic per element): 2 (default) =

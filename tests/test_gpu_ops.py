@@ -32,6 +32,9 @@ def h(t):  # half-rounded copy kept in f32 (what the kernel actually sees)
     return t.half().float()
 
 
+PV_DEFAULT = 1   # library default of vdn_flash_attn_set_pv_products (include/vdn.h); tests that change it put it back
+
+
 def close(got, ref, tol):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
@@ -489,13 +492,32 @@ def test_x3_heads_rope_and_flash(rt3):
         try:
             rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125)
         finally:
-            _abi.lib.vdn_flash_attn_set_pv_products(2)
+            _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
         close(out.float().reshape(B, P, C), ref, tol)
-    rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125, q8=q8, k8=k8)  # score cross terms on the 8-bit MFMA
+    _abi.lib.vdn_flash_attn_set_pv_products(2)
+    try:
+        rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125, q8=q8, k8=k8)  # score cross terms on the 8-bit MFMA
+    finally:
+        _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
     close(out.float().reshape(B, P, C), ref, 3e-4)
+    # one-product P V: the projection rounds V^T's hi plane to NEAREST (lo = remainder); the kernel reads hi alone
+    vt_ref = v.transpose(2, 3).reshape(B * Hh, 64, P).to(DEV)
+    got_hi = vd.hi[:, :, :P]
+    # round-to-nearest: half an fp16 ulp at most, and the same code as RN(reference) except where the fp32 accumulator
+    # and the fp64 reference straddle a rounding boundary (the toward-zero split differs in about half of the elements)
+    assert ((got_hi.float() - vt_ref).abs() <= vt_ref.abs() * 2.0 ** -11 * 1.01 + 1e-6).all()
+    assert (got_hi == vt_ref.half()).float().mean() > 0.99
+    close(vd.float().reshape(B, Hh, 64, tp)[:, :, :, :P], v.transpose(2, 3), 5e-6)
+    _abi.lib.vdn_flash_attn_set_pv_products(1)
+    try:
+        rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125, q8=q8, k8=k8)
+    finally:
+        _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
+    close(out.float().reshape(B, P, C), ref, 4e-4)
 
 
-@pytest.mark.parametrize("pv,tol,qk8,stream", [(3, 1e-5, False, 2), (2, 3e-4, False, 2), (2, 3e-4, True, 2), (2, 3e-4, True, 1)])
+@pytest.mark.parametrize("pv,tol,qk8,stream", [(3, 1e-5, False, 2), (2, 3e-4, False, 2), (2, 3e-4, True, 2), (2, 3e-4, True, 1),
+                                               (1, 4e-4, True, 2)])
 @pytest.mark.parametrize("nq,nk,gain", [(150, 200, 1.0), (1370, 1370, 1.0), (37, 64, 1.0), (70, 128, 1.0), (100, 130, 1.0),
                                         (129, 777, 6.0), (40, 8214, 1.0), (300, 321, 3.0)])
 def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
@@ -503,7 +525,8 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
     last tile; gain 6 makes row maxima jump by far more than the lazy-rescale threshold between tiles.
     pv = 3: P carried as hi/lo planes, fp32-faithful (1e-5 against fp64). pv = 2 (the default): every softmax weight
     rounded once to fp16 and normalised by the sum of the rounded weights: <= 2^-11 relative per weight, which on these
-    independent random V rows (the worst case: nothing in common to cancel) gives ~1e-4; end to end it is invisible
+    independent random V rows (the worst case: nothing in common to cancel) gives ~1e-4 (pv = 1 adds V's own fp16
+    rounding, 2^-12 per element, to that); end to end it is invisible
     (tests/test_gpu_e2e.py prints 4e-6..1e-5 either way). qk8: the score cross terms K_hi Q_lo^T + K_lo Q_hi^T on the
     block-scaled e5m2 MFMA from the 8-bit planes (built here as the projection epilogue builds them); its own error
     (~1e-5 of a logit) disappears under the pv = 2 rounding. stream: with the 8-bit planes, 2 = flash_attn2_kernel (the default:
@@ -522,9 +545,13 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
         s = rt3.to_half(src.to(DEV))
         dst.hi[:, :src.shape[1]] = s.hi
         dst.lo[:, :src.shape[1]] = s.lo
-    s = rt3.to_half(v.reshape(B * H, nk, 64).transpose(1, 2).contiguous().to(DEV))
+    vt = v.reshape(B * H, nk, 64).transpose(1, 2).contiguous().to(DEV)
+    s = rt3.to_half(vt)
     vd.hi[:, :, :nk] = s.hi
     vd.lo[:, :, :nk] = s.lo
+    if pv == 1:  # one-product P V reads the hi plane alone: rounded to nearest, as the projection writes it in that mode
+        vd.hi[:, :, :nk] = vt.half()
+        vd.lo[:, :, :nk] = (vt - vt.half().float()).half()
     out = rt3.hbuf("t2_o", (B * nq, H * 64))
     q8 = k8 = None
     if qk8:
@@ -540,7 +567,7 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
             rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125, q8=q8, k8=k8)
             assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
     finally:
-        _abi.lib.vdn_flash_attn_set_pv_products(2)
+        _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
         _abi.lib.vdn_flash_attn_set_stream(2)
 
 

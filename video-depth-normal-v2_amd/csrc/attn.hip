@@ -668,9 +668,15 @@ __global__ __launch_bounds__(256) void temporal_last_kernel(const float* __restr
   for (int e = 0; e < CPL; ++e) store_half(out, out_lo, (size_t)px * c + ch + e, o[e]);
 }
 
-// process-wide: MFMA products per P V term in split mode: 2 (default) or 3. VDN_ATTN_PV3=1 selects 3 at the first use.
+// process-wide: MFMA products per P V term in split mode: 1 (default), 2 or 3 (include/vdn.h). VDN_ATTN_PV = 1 | 2 | 3
+// (or the older VDN_ATTN_PV3=1) sets the default at the first use.
 int& pv_products() {
-  static int v = [] { const char* e = getenv("VDN_ATTN_PV3"); return (e && atoi(e) != 0) ? 3 : 2; }();
+  static int v = [] {
+    const char* e = getenv("VDN_ATTN_PV");
+    if (e && atoi(e) >= 1 && atoi(e) <= 3) return atoi(e);
+    e = getenv("VDN_ATTN_PV3");
+    return (e && atoi(e) != 0) ? 3 : 1;
+  }();
   return v;
 }
 
@@ -694,8 +700,11 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
   else if (Ql && q8 && k8 && DT == VDN_F16) {
     if constexpr (DT == VDN_F16) {
-      if (attn_stream() == 2)
-        hipLaunchKernelGGL(flash_attn2_kernel, grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
+      if (attn_stream() == 2 && pv_products() == 1)
+        hipLaunchKernelGGL(flash_attn2_kernel<1>, grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
+                           (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+      else if (attn_stream() == 2)
+        hipLaunchKernelGGL(flash_attn2_kernel<2>, grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
                            (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
       else
       hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
@@ -733,7 +742,7 @@ int temporal_launch(const void* qkv, void* out, const void* qkv_lo, void* out_lo
 }  // namespace
 
 extern "C" int vdn_flash_attn_set_pv_products(int n) {
-  if (n != 2 && n != 3) return VDN_EINVAL;
+  if (n < 1 || n > 3) return VDN_EINVAL;
   pv_products() = n;
   return VDN_OK;
 }

@@ -15,6 +15,9 @@
 //
 // Included by attn.hip (helpers perm23 / acc_key / xhalf / stage_barrier and the Half<> traits come from there).
 
+// PV: MFMA products per P V term: 2 = P~ (V_hi + V_lo), 1 = P~ V_hi with V_hi rounded to nearest by the producer
+// (vdn_gemm rounds the hi plane of transposed head splits that way): 8 MFMAs, 8 fragment reads and 2 LDS-DMA pieces fewer per tile.
+template <int PV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn2_kernel(
     const _Float16* __restrict__ Q, const _Float16* __restrict__ K, const _Float16* __restrict__ Vt, _Float16* __restrict__ out,
     const _Float16* __restrict__ Kl, const _Float16* __restrict__ Vtl, _Float16* __restrict__ outl, const uint8_t* __restrict__ Q8,
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (t * 64 + kb * 32 + acc_key(i, h) >= nk) sc[kb][i] = -INFINITY;
       }
     }
-    V8 fr[4];
+    V8 fr[8];  // fragment ring (the generated stream uses lookahead + 1 of them)
     i32x8 f8[2];
     float mx = -1e30f, alpha = 1.f, mb = 0.f, ls0 = 0.f, ls1 = 0.f;
     float ff[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, fe[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -198,7 +201,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto vlr = [&]() { l_run = l_run * alpha + (ls0 + ls1); A2_PIN(l_run); };
     auto dma = [&](auto ic) {  // the iteration's 8 LDS-DMA pieces of this wave: V_t (4), K_{t+2} (4)
       constexpr int i = decltype(ic)::value;
-      if constexpr (i < 4) stage_v_piece(PAR, t, i >> 1, i & 1);
+      if constexpr (i < 4) {
+        if constexpr (PV == 2 || !(i & 1)) stage_v_piece(PAR, t, i >> 1, i & 1);
+      }
       else if constexpr (HAS_NEXT) stage_k_piece(PAR, tk, (i - 4) >> 1, i & 1);
     };
 #if VDN_ATTN_ABL & 16  // timing ablations (attn.hip): no fragment reads / no MFMA / no softmax VALU / no LDS-DMA
@@ -247,7 +252,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #include "attn2_stream_stamps.inc"
 #undef A2_STAMP
 #else
-#include "attn2_stream.inc"
+#ifndef VDN_ATTN2_INC
+#define VDN_ATTN2_INC "attn2_stream.inc"
+#endif
+    if constexpr (PV == 1) {
+#include "attn2_stream_pv1.inc"
+    } else {
+#include VDN_ATTN2_INC
+    }
 #endif
 #undef A2_LDV
 #undef A2_LDK
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           o[db] = HT::mfma32(*(const V8*)(sV + v_addr(db, c)), p[c >> 1][c & 1], o[db]);
-          o[db] = HT::mfma32(*(const V8*)(sV + 2 * TILE + v_addr(db, c)), p[c >> 1][c & 1], o[db]);
+          if constexpr (PV == 2) o[db] = HT::mfma32(*(const V8*)(sV + 2 * TILE + v_addr(db, c)), p[c >> 1][c & 1], o[db]);
         }
     };
     if ((nt - 1) & 1) pv_last(pf[1]);

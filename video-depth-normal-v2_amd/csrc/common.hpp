@@ -211,6 +211,13 @@ __device__ __forceinline__ void store_half(T* hi, T* lo, size_t i, float v) {
   if (lo) { T a, b; split_rtz(v, a, b); hi[i] = a; lo[i] = b; }
   else hi[i] = (T)v;
 }
+// hi rounded to NEAREST, lo = the remainder (hi + lo as exact as the toward-zero split; the planes may differ in sign)
+template <typename T>
+__device__ __forceinline__ void store_half_nearest(T* hi, T* lo, size_t i, float v) {
+  const T a = (T)v;
+  hi[i] = a;
+  if (lo) lo[i] = (T)(v - (float)a);
+}
 template <typename T>
 __device__ __forceinline__ float load_half(const T* hi, const T* lo, size_t i) {
   return lo ? (float)hi[i] + (float)lo[i] : (float)hi[i];

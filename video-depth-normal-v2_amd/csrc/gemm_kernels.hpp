@@ -179,8 +179,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const size_t o = (hb * 64 + e0 + e) * p.tpad + tk;
-        dst[o] = h[e];
-        dlo[o] = l[e];
+        store_half_nearest(dst, dlo, o, a[e]);  // V^T: hi to nearest (the one-product P V reads it alone), lo = remainder
       }
     } else {
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
@@ -280,7 +279,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
       }
       if (p.transposed[split]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) store_half(dst, dlo, (hb * 64 + 2 * pi + e) * p.tpad + tk, o8[e]);
+        for (int e = 0; e < 8; ++e) store_half_nearest(dst, dlo, (hb * 64 + 2 * pi + e) * p.tpad + tk, o8[e]);
       } else {
         const size_t o = (hb * p.tpad + tk) * 64 + 2 * pi;
         typename H::V8 h8, l8;
@@ -303,7 +302,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     }
     if (p.transposed[split]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) store_half(dst, dlo, (hb * 64 + e0 + e) * p.tpad + tk, a[e]);
+      for (int e = 0; e < 4; ++e) store_half_nearest(dst, dlo, (hb * 64 + e0 + e) * p.tpad + tk, a[e]);
     } else {
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
       typename H::V4 h, l;
@@ -386,8 +385,7 @@ __device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const size_t o = (hb * 64 + e0 + e) * p.tpad + tk;
-        dst[o] = h[e];
-        dlo[o] = l[e];
+        store_half_nearest(dst, dlo, o, a[e]);  // V^T: hi to nearest (the one-product P V reads it alone), lo = remainder
       }
     } else {
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
