@@ -379,7 +379,8 @@ def main():
             tf = tot_fl / (tot_ms * 1e-3) / 1e12
             out["attention_kernel"] = {"avg_launch_ms": round(tot_ms / len(att), 4), "achieved_tflops": round(tf, 2),
                                        "frac_of_mfma_peak": round(tf / PEAK_TFLOPS_F16, 4),
-                                       "executed_frac": round(nprod * tf / PEAK_TFLOPS_F16, 4)}
+                                       "note": "algorithmic flops (4 nq nk 64 per head) / HIP-event time; the kernel issues 1 fp16 + 2 "
+                                               "block-scaled 8-bit products for QK^T and attention_pv_products for P V"}
 
     # ---------------- the same workload on ONE GPU (rank 0 alone) next to the N-GPU number of the strong-scaling run
     if strong and dist is not None and not a.stub:
