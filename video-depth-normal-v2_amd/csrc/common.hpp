@@ -49,19 +49,16 @@ template <> struct Half<VDN_BF16> {
   }
 };
 
-// ReLU on 8 packed 16-bit floats held as 4 dwords: clear every lane whose sign bit is set
-// (works for fp16 and bf16 alike; -0 -> +0, NaN with sign -> 0 which matches max(x,0) closely
-// enough for activations that are finite by construction).
+// ReLU on 8 packed 16-bit floats held as 4 dwords, ONE instruction per dword: as signed 16-bit integers every value
+// with the sign bit set is negative, so v_pk_max_i16(x, 0) clears exactly those (fp16 and bf16 alike; -0 -> +0, +NaN and
+// +inf pass through like in torch.relu, a NaN with the sign bit becomes 0). The ReLU-on-load of the convolutions runs
+// beside the MFMAs of the main loop: 4 VALU per dword (and / shift / multiply / and-not) cost the 256 x 256 kernel 0.7 us
+// of its 2.7 us per K step.
 template <typename V8>
 __device__ __forceinline__ V8 relu8(V8 v) {
-  u32x4 u = __builtin_bit_cast(u32x4, v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint32_t s = u[i] & 0x80008000u;          // sign bits of both halves
-    uint32_t m = (s >> 15) * 0xFFFFu;         // 0xFFFF in each half whose sign is set
-    u[i] &= ~m;
-  }
-  return __builtin_bit_cast(V8, u);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(V8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {  // nn.GELU() default (exact erf form)
