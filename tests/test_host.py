@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -154,3 +155,52 @@ def test_oracle_cubic_resize_matches_torch_bicubic():
     x, _ = O.image2tensor(same, 28)
     want = (np.array([30, 20, 10]) / 255.0 - np.array([0.485, 0.456, 0.406])) / np.array([0.229, 0.224, 0.225])
     assert np.allclose(x[0].mean((1, 2)).numpy(), want, atol=1e-6)
+
+
+@pytest.mark.parametrize("inc,args,n_mfma", [("attn2_stream.inc", [], 28), ("attn2_stream_pv1.inc", ["--pv", "1"], 20),
+                                             ("attn2_stream_stamps.inc", ["--stamps"], 28)])
+def test_generated_attention_stream_is_current_and_well_formed(inc, args, n_mfma):
+    """csrc/attn2_stream*.inc are GENERATED (tools/gen_attn_stream.py): the committed files equal the generator's output for
+    the documented arguments, and the stream obeys the rules the kernel relies on: every MFMA's operand fragment is loaded
+    into its ring buffer at least one MFMA EARLIER (or before the first one) and not overwritten before the MFMA issues, every softmax piece appears exactly
+    once with F_p before X_p before C_p, the row maximum / rescale test precede the first F, each LDS-DMA piece once."""
+    import re
+    import subprocess
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_stream.py"), "--dma-first-gap", "0", "--dma-stride", "1"] + args,
+                         capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(ROOT, "video-depth-normal-v2_amd", "csrc", inc)) as f:
+        assert f.read() == gen, f"{inc} is stale: regenerate with tools/gen_attn_stream.py"
+    calls = re.findall(r"A2_(\w+)\(([^)]*)\)", gen)
+    live4, live8, seen, gap, loaded_gap = {}, {}, [], -1, {}
+    mfmas = 0
+    for name, a in calls:
+        arg = [int(x) for x in a.split(",")] if a.strip() else []
+        if name in ("LDV", "LDK"):
+            live4[arg[-1]] = (name, tuple(arg[:-1])); loaded_gap[("4", arg[-1])] = gap
+        elif name == "LDK8":
+            live8[arg[-1]] = tuple(arg[:-1]); loaded_gap[("8", arg[-1])] = gap
+        elif name == "PV":
+            c, db, buf = arg
+            assert live4[buf][0] == "LDV" and live4[buf][1][:2] == (c, db) and (loaded_gap[("4", buf)] < gap or loaded_gap[("4", buf)] == -1)
+            mfmas += 1; gap += 1
+        elif name == "QK":
+            kb, ks, buf, first = arg
+            assert live4[buf] == ("LDK", (kb, ks)) and (loaded_gap[("4", buf)] < gap or loaded_gap[("4", buf)] == -1)
+            mfmas += 1; gap += 1
+        elif name == "QX":
+            kb, lo, buf, first = arg
+            assert live8[buf] == (kb, lo) and (loaded_gap[("8", buf)] < gap or loaded_gap[("8", buf)] == -1)
+            mfmas += 1; gap += 1
+        elif name in ("F", "X", "C", "MAX", "DMA"):
+            seen.append((name, arg[0]))
+        elif name in ("XH", "BP", "LR"):
+            seen.append((name, -1))
+    assert mfmas == n_mfma
+    order = {k: i for i, k in enumerate(seen)}
+    assert len(order) == len(seen)                                            # nothing twice
+    for p_ in range(16):
+        assert order[("F", p_)] < order[("X", p_)] < order[("C", p_)]
+        assert order[("BP", -1)] < order[("F", p_)]
+    assert all(order[("MAX", q)] < order[("XH", -1)] < order[("BP", -1)] for q in range(4)) and order[("C", 15)] < order[("LR", -1)]
+    dma = sorted(a for n, a in seen if n == "DMA")
+    assert dma == (list(range(8)) if "--pv" not in args else [0, 2, 4, 5, 6, 7])
