@@ -110,6 +110,8 @@ def test_two_rank_exchange_and_plane_staging(port):
     (3, 20, 29613, [(0, 0, 2)], False),
     (2, 50, 29614, [(0, 0, 1), (1, 1, 1), (2, 0, 2)], True),
     (3, 20, 29615, [(0, 0, 2)], True),
+    # BASELINE configs[3] itself: the 256-frame clip on 8 ranks = 8 whole windows + 4 windows frame-sharded over rank pairs
+    (8, 256, 29616, [(w, w, 1) for w in range(8)] + [(8, 0, 2), (9, 2, 2), (10, 4, 2), (11, 6, 2)], False),
 ])
 def test_hybrid_schedule_driver_gloo(world, n, port, expect, staged):
     mgr = mp.Manager()
