@@ -252,6 +252,21 @@ def test_infer_video_depth_windows_and_stitch():
     assert np.allclose(d, host, rtol=2e-5, atol=1e-6), float(np.abs(d - host).max())
 
 
+def test_clip_result_through_pinned_memory_is_never_overwritten_while_held():
+    """vdn.util.to_host: the drivers' device-to-host copy reuses one pinned buffer, but only after the caller dropped the
+    previous result."""
+    from vdn import util
+    a = torch.arange(6, dtype=torch.float32, device="cuda").reshape(2, 3)
+    r1 = util.to_host(a)
+    r2 = util.to_host(a + 10)          # r1 is still alive: a second buffer
+    assert r1.tolist() == [[0, 1, 2], [3, 4, 5]] and r2.tolist() == [[10, 11, 12], [13, 14, 15]]
+    p2 = r2.ctypes.data
+    del r2
+    r3 = util.to_host(a + 20)          # the dropped result's buffer is reused
+    assert r3.ctypes.data == p2 and r3.tolist() == [[20, 21, 22], [23, 24, 25]] and r1.tolist() == [[0, 1, 2], [3, 4, 5]]
+    assert util.to_host(torch.ones(2)).tolist() == [1, 1]   # CPU tensors pass through
+
+
 def test_image2tensor_and_infer_image_against_oracle():
     """a1 + a12 (depth_anything_v2.py:57-92): BGR u8 image -> cubic resize to the 14-multiple lower bound -> normalise ->
     forward -> bilinear back to the image size, against the oracle's restatement of the same pipeline (its cubic resize

@@ -318,7 +318,7 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
             out = torch.empty((n, fh, fw), dtype=torch.float32, device=dev)
         out = out.contiguous()
         broadcast_from(out, src=0)
-    return (None if out is None else out.cpu().numpy()), target_fps
+    return (None if out is None else util.to_host(out.contiguous())), target_fps
 
 
 # --------------------------------------------------------------------------------------------- frames

@@ -183,7 +183,7 @@ class VideoDepthAnything(_EngineOwner):
         st = DeviceStitcher(rt, len(table), fh, fw)
         for d in self.window_depths(net_in, table):
             st.push(self.resize_depth(d, fh, fw))  # [32,fh,fw], stays on the device
-        return st.result(n).cpu().numpy(), target_fps  # the clip's only device-to-host copy
+        return util.to_host(st.result(n)), target_fps  # the clip's only device-to-host copy (pinned buffer)
 
     # bytes of encoder taps one frame keeps in the clip-level cache: 4 taps x P tokens x C channels x 16-bit planes
     def _tap_bytes_per_frame(self, H: int, W: int) -> int:
