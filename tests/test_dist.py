@@ -150,6 +150,16 @@ def test_schedule_and_payload():
     for dst in range(8):
         got = sorted(f for src in range(8) for f in send[src][dst])
         assert got == need[dst] and all(f in local[src] for src in range(8) for f in send[src][dst])
+    # frames are encoded where they are read when possible: a rank's heads read 45..48 frames, 32 of them its own
+    recv = [sum(len(send[src][dst]) for src in range(8) if src != dst) for dst in range(8)]
+    assert max(recv) <= 20 and all(recv[d] == len(need[d]) - len(set(need[d]) & set(local[d])) for d in range(8))
+    for P, bound in ((2, 16), (4, 16)):                              # whole windows only: contiguous runs of windows per rank
+        t2 = util.window_table(256)
+        j2 = plan_schedule(len(t2), P)
+        assert [j[1] for j in j2] == sorted(j[1] for j in j2)        # rank r owns windows r*k .. r*k+k-1
+        _, per2, loc2, need2, send2 = tap_exchange_plan(t2, j2, P)
+        assert all(len(l) == per2 for l in loc2)
+        assert max(sum(len(send2[s][d]) for s in range(P) if s != d) for d in range(P)) <= bound   # was 92 / 77 with round-robin windows
     ex = FrameShardExchange(32)      # world size 1: identity exchange
     x = torch.randn(32, 10, 4)
     assert ex.frames_to_pixels(x) is x and ex.pixels_to_frames(x, 10) is x

@@ -105,12 +105,15 @@ def window_owner(n_windows: int, nranks: int) -> List[int]:
 
 def plan_schedule(n_windows: int, nranks: int, frames_per_window: int = util.INFER_LEN) -> List[Tuple[int, int, int]]:
     """Jobs (window, first_rank, group_size) in execution order. Whole windows (group_size 1) fill the full
-    rounds; the `n_windows % nranks` windows of the last round are each sharded by frame over a group of
-    `group_size` consecutive ranks (a power of two that divides the frames of a window)."""
+    rounds: rank r owns the CONTIGUOUS run of `n_windows // nranks` windows r*k .. r*k + k - 1 (neighbouring windows
+    share 10 of their 32 frames and a rank's windows then read one stretch of the clip, so most of the encoder taps its
+    heads need are the ones it encoded itself); the `n_windows % nranks` windows of the last round are each sharded by
+    frame over a group of `group_size` consecutive ranks (a power of two that divides the frames of a window)."""
     jobs = []
-    full = (n_windows // nranks) * nranks
+    k = n_windows // nranks
+    full = k * nranks
     for w in range(full):
-        jobs.append((w, w % nranks, 1))
+        jobs.append((w, w // k, 1))
     rem = n_windows - full
     if rem:
         g = 1
@@ -148,20 +151,29 @@ def _subgroups(nranks: int, g: int):
 # --------------------------------------------------------------------------------------------- driver
 def tap_exchange_plan(table, jobs, nranks: int, T: int = util.INFER_LEN):
     """Who encodes which frame and who needs which frame's encoder taps (a pure function of the window table and
-    the schedule, identical on every rank). Distinct frames are split into contiguous blocks, one per rank (the
-    encoder is per-frame, so this is perfectly balanced: 256 frames / 8 ranks = 32 each, not 48 = 1.5 windows);
-    rank r then needs the frames of its head jobs. Returns (frames, per, local[r], need[r], send[src][dst])."""
+    the schedule, identical on every rank). Every distinct frame is encoded ONCE, at most ceil(frames / ranks) per rank
+    (the encoder is per-frame, so this is perfectly balanced: 256 frames / 8 ranks = 32 each, not 48 = 1.5 windows), and
+    preferably by a rank whose own head jobs read it: frames are dealt in ascending order to the least loaded rank that
+    needs them, else to the least loaded rank at all. On 8 ranks 32 of the 45..48 frames a rank's heads read are then
+    its own. Returns (frames, per, local[r], need[r], send[src][dst])."""
     frames = sorted({f for row in table for f in row})
     per = (len(frames) + nranks - 1) // nranks
-    pos = {f: i for i, f in enumerate(frames)}
-    local = [frames[r * per:(r + 1) * per] for r in range(nranks)]
     need = [[] for _ in range(nranks)]
     for (w, r0, g) in jobs:
         Tl = T // g
         for k in range(g):
             need[r0 + k] += table[w][k * Tl:(k + 1) * Tl]
     need = [sorted(set(n)) for n in need]
-    send = [[[f for f in need[dst] if pos[f] // per == src] for dst in range(nranks)] for src in range(nranks)]
+    wants = [set(n) for n in need]
+    count = [0] * nranks
+    owner = {}
+    for f in frames:
+        cands = [r for r in range(nranks) if f in wants[r] and count[r] < per] or [r for r in range(nranks) if count[r] < per]
+        r = min(cands, key=lambda q: (count[q], q))
+        owner[f] = r
+        count[r] += 1
+    local = [[f for f in frames if owner[f] == r] for r in range(nranks)]
+    send = [[[f for f in need[dst] if owner[f] == src] for dst in range(nranks)] for src in range(nranks)]
     return frames, per, local, need, send
 
 
