@@ -1,3 +1,4 @@
+"""Host <-> device copy rates on the GPU box (pageable vs pinned): the numbers behind vdn.util.to_host (profiles/r02_d2h_probe.log)."""
 import time, torch
 x = torch.randn(256, 518, 518, device="cuda")
 torch.cuda.synchronize()
