@@ -24,7 +24,8 @@ def synth_sd(which: str, enc: str):
     sch = schema(which, enc)
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict([(k, tuple(s)) for k, s in sch["params"]], SEED).items()}
     for k, s in sch["buffers"]:
-        sd[k] = O.temporal_pe(s[-1], s[1])
+        b = synth.synth_buffer(SEED, k, tuple(s))   # BatchNorm statistics of the use_bn head ("Af" / "Bf" schemas)
+        sd[k] = torch.from_numpy(np.asarray(b)) if b is not None else O.temporal_pe(s[-1], s[1])
     return sd
 
 

@@ -15,20 +15,21 @@ TOL = 1e-3
 
 def _product(which, enc, precision=None):
     import vdn
-    cls = vdn.DepthAnythingV2 if which == "A" else vdn.VideoDepthAnything
-    m = cls(**vdn.MODEL_CONFIGS[enc])
+    cls = vdn.DepthAnythingV2 if which[0] == "A" else vdn.VideoDepthAnything
+    flags = dict(use_bn=True, use_clstoken=True) if which.endswith("f") else {}   # "Af" / "Bf": the two optional constructor flags
+    m = cls(**dict(vdn.MODEL_CONFIGS[enc], **flags))
     m.load_state_dict(synth_sd(which, enc), strict=True)
     if precision:
         m.set_precision(precision)
     return m.to("cuda").eval()
 
 
-def _stream_A(name, enc, oracle_steps):
+def _stream_A(name, enc, oracle_steps, which="A"):
     from oracle import ref_cpu as O
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     B, steps, H, W, sub, _ = [int(v) for v in g["meta"]]
-    model = _product("A", enc)
-    sd = synth_sd("A", enc)
+    model = _product(which, enc)
+    sd = synth_sd(which, enc)
     x = inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
     kept = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("pre_") and not k.startswith("pre_stats"))
     mem = O.MemoryState(6)
@@ -67,6 +68,13 @@ def test_A_vitl_518_stream_fill_and_evict():
     """BASELINE configs[1] at batch 1: ViT-L, 8 frames on one memory bank — every depth S = 0..6, then one eviction —
     against the fixture written by the imported reference (frames 0, 1, 6, 7 kept)."""
     _stream_A("A_vitl_518", "vitl", oracle_steps=1)
+
+
+def test_A_use_bn_and_use_clstoken():
+    """DepthAnythingV2(use_bn=True, use_clstoken=True): BatchNorm (non-trivial running statistics) folded into the fusion
+    blocks' convolutions, cls-token readout on taps 0-2 after the encoder and on the memory block's output for tap 3
+    (dpt.py:81-88,119-123; util/blocks.py:49-51,71-77), three frames on one memory bank against the reference fixture."""
+    _stream_A("Af_vits_266", "vits", oracle_steps=2, which="Af")
 
 
 def test_A_vitb_266_stream():
@@ -163,11 +171,11 @@ def test_memory_bank_rejects_a_batch_change_until_cleared():
     assert torch.isfinite(model.forward(x.cuda())).all()
 
 
-def _clip_B(name, enc, use_oracle):
+def _clip_B(name, enc, use_oracle, which="B"):
     from oracle import ref_cpu as O
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     _, T, H, W, sub, _ = [int(v) for v in g["meta"]]
-    model = _product("B", enc)
+    model = _product(which, enc)
     x = inputs(T, H, W).reshape(1, T, 3, H, W)
     pre = model.forward(x.cuda(), _pre_relu=True)[0].cpu()
     assert torch.isfinite(pre).all()
@@ -182,7 +190,7 @@ def _clip_B(name, enc, use_oracle):
     assert np.allclose(means, g["pre_stats_all"][:, 0], rtol=5e-3, atol=2e-3)
     if use_oracle:
         with torch.no_grad():
-            ref = O.video_depth_anything_forward(synth_sd("B", enc), x, enc, pre_relu=True)[0]
+            ref = O.video_depth_anything_forward(synth_sd(which, enc), x, enc, pre_relu=True)[0]
         e = rel_l2(torch.relu(pre), torch.relu(ref))
         print(f"[{name}] all {T} frames vs oracle post-ReLU {e:.2e}")
         assert e < TOL
@@ -190,6 +198,12 @@ def _clip_B(name, enc, use_oracle):
 
 def test_B_vits_full_window():
     _clip_B("B_vits_518", "vits", use_oracle=True)
+
+
+def test_B_use_bn_and_use_clstoken():
+    """VideoDepthAnything(use_bn=True, use_clstoken=True): the readout is per frame, so every tap gets it right after the
+    encoder (also in the tap cache, the streaming and the sharded drivers); 4-frame clip against the reference fixture."""
+    _clip_B("Bf_vits_266", "vits", use_oracle=True, which="Bf")
 
 
 def test_B_vits_nonsquare_short_clip():

@@ -90,12 +90,13 @@ def test_gemm_argument_validation_without_gpu():
     assert _abi.lib.vdn_gemm(ctypes.byref(d), None) == -2
 
 
-@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitb"), ("A", "vitl"), ("B", "vits"), ("B", "vitl")])
+@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitb"), ("A", "vitl"), ("B", "vits"), ("B", "vitl"), ("Af", "vits"), ("Bf", "vits")])
 def test_state_dict_schema_matches_reference(which, enc):
-    """Drop-in contract: same parameter/buffer keys and shapes as the reference classes."""
+    """Drop-in contract: same parameter/buffer keys and shapes as the reference classes; "Af" / "Bf" = the
+    same classes built with use_bn=True, use_clstoken=True (BatchNorm parameters and buffers, readout_projects)."""
     import vdn
-    cls = vdn.DepthAnythingV2 if which == "A" else vdn.VideoDepthAnything
-    m = cls(**vdn.MODEL_CONFIGS[enc])
+    cls = vdn.DepthAnythingV2 if which[0] == "A" else vdn.VideoDepthAnything
+    m = cls(**dict(vdn.MODEL_CONFIGS[enc], **(dict(use_bn=True, use_clstoken=True) if which.endswith("f") else {})))
     sch = schema(which, enc)
     assert {k: tuple(v.shape) for k, v in m.named_parameters()} == {k: tuple(s) for k, s in sch["params"]}
     assert {k: tuple(v.shape) for k, v in m.named_buffers()} == {k: tuple(s) for k, s in sch["buffers"]}

@@ -12,10 +12,10 @@ from oracle import ref_cpu as O
 TOL = 2e-5
 
 
-def _run_A(name, enc, check_steps=None):
+def _run_A(name, enc, check_steps=None, which="A"):
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     B, steps, H, W, sub, _ = [int(v) for v in g["meta"]]
-    sd = synth_sd("A", enc)
+    sd = synth_sd(which, enc)
     x = inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
     mem = O.MemoryState(6)
     kept = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("pre_") and not k.startswith("pre_stats"))
@@ -54,10 +54,10 @@ def test_oracle_A_vitb_and_stage_fixtures():
     _run_A("G_vits_392", "vits")
 
 
-def _run_B(name, enc):
+def _run_B(name, enc, which="B"):
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     _, T, H, W, sub, _ = [int(v) for v in g["meta"]]
-    sd = synth_sd("B", enc)
+    sd = synth_sd(which, enc)
     x = inputs(T, H, W).reshape(1, T, 3, H, W)
     tr = {}
     with torch.no_grad():
@@ -71,6 +71,13 @@ def _run_B(name, enc):
         assert rel_l2(v.reshape(-1)[sample_idx(v.numel())], g[f"mm{i}_samp"]) < TOL
     means = np.array([pre[t].mean().item() for t in range(T)])
     assert np.allclose(means, g["pre_stats_all"][:, 0], rtol=1e-3, atol=1e-4)
+
+
+def test_oracle_use_bn_and_use_clstoken():
+    """The two constructor flags no shipped configuration enables (dpt.py:81-88,119-123; util/blocks.py:49-51,71-77):
+    fixtures from the imported reference built with use_bn=True, use_clstoken=True and non-trivial BatchNorm statistics."""
+    _run_A("Af_vits_266", "vits", which="Af")
+    _run_B("Bf_vits_266", "vits", which="Bf")
 
 
 def test_oracle_B_vits_full_window():

@@ -72,6 +72,10 @@ def load_synth(model: torch.nn.Module):
     new = synth.synth_state_dict(shapes, SEED)
     for k, v in new.items():
         sd[k] = torch.from_numpy(v)
+    for k, v in model.named_buffers():   # BatchNorm statistics of the use_bn head: non-trivial, deterministic
+        b = synth.synth_buffer(SEED, k, tuple(v.shape))
+        if b is not None:
+            sd[k] = torch.from_numpy(np.asarray(b))
     model.load_state_dict(sd, strict=True)
     return {k: v.detach().clone() for k, v in model.state_dict().items()}, shapes
 
@@ -123,14 +127,14 @@ class StageHooks:
         sc.output_conv1.register_forward_hook(lambda m, i, o: self.v.update(oc1=o.detach().permute(0, 2, 3, 1).contiguous()))
 
 
-def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str, stages: bool = False):
+def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str, stages: bool = False, flags: dict = None):
     from depth_anything_v2.depth_anything_v2 import DepthAnythingV2
     from oracle import ref_cpu as O
-    cfg = O.MODEL_CONFIGS[enc]
+    cfg = dict(O.MODEL_CONFIGS[enc], **(flags or {}))
     torch.manual_seed(0)
     model = DepthAnythingV2(**cfg).eval()
     sd, shapes = load_synth(model)
-    with open(os.path.join(GOLD, f"schema_A_{enc}.json"), "w") as f:
+    with open(os.path.join(GOLD, f"schema_A{'f' if flags else ''}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
     x_all = make_inputs(B * steps, H, W).reshape(steps, B, 3, H, W)
@@ -180,14 +184,14 @@ def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, na
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
-def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str):
+def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str, flags: dict = None):
     from video_depth_anything.video_depth import VideoDepthAnything
     from oracle import ref_cpu as O
-    cfg = O.MODEL_CONFIGS[enc]
+    cfg = dict(O.MODEL_CONFIGS[enc], **(flags or {}))
     torch.manual_seed(0)
     model = VideoDepthAnything(**cfg).eval()
     sd, shapes = load_synth(model)
-    with open(os.path.join(GOLD, f"schema_B_{enc}.json"), "w") as f:
+    with open(os.path.join(GOLD, f"schema_B{'f' if flags else ''}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
     x = make_inputs(T, H, W).reshape(1, T, 3, H, W)
@@ -410,6 +414,9 @@ JOBS = {
     # ViT-B (never tested before) + the stage fixtures G2 / G4 of SURVEY.md §8c
     "A_vitb_266": lambda: gen_A("vitb", 266, 266, 1, 3, [0, 1, 2], 1, "A_vitb_266", stages=True),
     "G_vits_392": lambda: gen_A("vits", 392, 392, 1, 2, [0, 1], 2, "G_vits_392", stages=True),
+    # the two constructor flags no shipped configuration enables: BatchNorm in the fusion blocks, cls-token readout
+    "Af_vits_266": lambda: gen_A("vits", 266, 266, 1, 3, [0, 1, 2], 1, "Af_vits_266", flags=dict(use_bn=True, use_clstoken=True)),
+    "Bf_vits_266": lambda: gen_B("vits", 266, 266, 4, [0, 3], 1, "Bf_vits_266", flags=dict(use_bn=True, use_clstoken=True)),
     # BASELINE configs[1]: ViT-L stream through every memory depth S = 0..6 and one eviction
     "A_vitl_518": lambda: gen_A("vitl", 518, 518, 1, 8, [0, 1, 6, 7], 4, "A_vitl_518"),
     "B_vitl_518": lambda: gen_B("vitl", 518, 518, 4, [0, 3], 4, "B_vitl_518"),

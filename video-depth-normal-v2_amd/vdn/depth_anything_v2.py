@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import modules, util
-from .engine import DPTEngine, EncoderEngine, MemoryEngine
+from .engine import DPTEngine, EncoderEngine, MemoryEngine, ReadoutEngine
 from .runtime import Runtime
 
 _MEAN = (0.485, 0.456, 0.406)
@@ -82,15 +82,13 @@ class DepthAnythingV2(_EngineOwner):
     def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False,
                  use_clstoken=False, max_memory_length=6):
         super().__init__()
-        if use_bn or use_clstoken:
-            raise NotImplementedError("use_bn / use_clstoken are never enabled by the reference configs (run_video.py:28-33)")
         self.intermediate_layer_idx = {k: v["taps"] for k, v in modules.ENCODERS.items()}
         self.encoder = encoder
         cfg = modules.ENCODERS[encoder]
         self.max_memory_length = max_memory_length
         self.pretrained = modules.dinov2(encoder)
         self.memory_block = modules.memory_block(cfg["dim"], max_memory_length, 4)
-        self.depth_head = modules.dpt_head(cfg["dim"], features, out_channels)
+        self.depth_head = modules.dpt_head(cfg["dim"], features, out_channels, use_bn, use_clstoken)
         self._features, self._out_channels = features, list(out_channels)
 
     def _engines(self):
@@ -101,6 +99,8 @@ class DepthAnythingV2(_EngineOwner):
                 rt=rt, enc=EncoderEngine(rt, self.pretrained, cfg),
                 mem=MemoryEngine(rt, self.memory_block, cfg["dim"], self.max_memory_length),
                 head=DPTEngine(rt, self.depth_head, cfg["dim"], self._features, self._out_channels, temporal=False))
+            if hasattr(self.depth_head, "readout_projects"):   # use_clstoken
+                self._eng["enc"].readout = ReadoutEngine(rt, self.depth_head.readout_projects, cfg["dim"])
             self._lanes = None
         return self._eng
 
@@ -118,6 +118,9 @@ class DepthAnythingV2(_EngineOwner):
                 rt = e["rt"] if i == 0 else Runtime(e["rt"].device, e["rt"].half, e["rt"].split)
                 enc, mem, head = (copy.copy(e[k]) for k in ("enc", "mem", "head"))
                 enc.rt = mem.rt = head.rt = rt
+                if getattr(enc, "readout", None) is not None:
+                    enc.readout = copy.copy(enc.readout)
+                    enc.readout.rt = rt
                 mem.lane, mem._nomem = (i, n), {}   # bank state, ring and RoPE table stay shared (built in prepare())
                 if i > 0:  # lazily built per-lane tables are built on the lane's own stream
                     enc._pos_cache = {}
@@ -134,7 +137,10 @@ class DepthAnythingV2(_EngineOwner):
         B = x.shape[0]
         taps, last_f32, (ph, pw) = enc.run(x, want_f32_last=True)
         fm = mem.forward(last_f32, B, ph * pw)
-        depth = head.run([taps[0], taps[1], taps[2], fm], B, ph, pw, relu=not _pre_relu)
+        t3 = fm   # the memory bank is updated with fm itself (depth_anything_v2.py:52-54); the readout happens inside the head
+        if getattr(enc, "readout", None) is not None:   # use_clstoken: the memory output takes the last tap's readout (dpt.py:119-123)
+            t3 = enc.readout.apply(3, fm, enc.cls_last, B, ph * pw, rt.hbuf("ro_fm", (B * ph * pw, enc.C)))
+        depth = head.run([taps[0], taps[1], taps[2], t3], B, ph, pw, relu=not _pre_relu)
         out = depth.clone()
         if _pre_relu:
             depth.clamp_(min=0)

@@ -93,6 +93,7 @@ class EncoderEngine:
         f1 = rt.hbuf("enc_fc1", (M, 4 * C))
         heads = dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
         outs, last_f32 = [], None
+        readout = getattr(self, "readout", None)   # ReadoutEngine when the head was built with use_clstoken
         probe = getattr(self, "probe", None)   # tests only: callable(block index, fp32 token stream [M, C]); -1 = input of block 0
         if probe is not None:
             probe(-1, tok)
@@ -112,9 +113,45 @@ class EncoderEngine:
                 f = None
                 if want_f32_last and j == len(self.taps) - 1:
                     f = last_f32 = rt.fbuf("tap_last_f32", (Bf * P, C))
-                rt.layernorm(tok, M, C, self.nw, self.nb, 1e-6, out_h=t, out_f=f, out_group=N)
+                if readout is None:
+                    rt.layernorm(tok, M, C, self.nw, self.nb, 1e-6, out_h=t, out_f=f, out_group=N)
+                else:
+                    # the final-normed cls row of every frame, then the readout projection on the normed patch tokens;
+                    # with want_f32_last (path A) the last tap goes through the memory block first: its readout is the caller's
+                    last = want_f32_last and j == len(self.taps) - 1
+                    raw = t if last else rt.hbuf("tap_raw", (Bf * P, C))
+                    rt.layernorm(tok, M, C, self.nw, self.nb, 1e-6, out_h=raw, out_f=f, out_group=N)
+                    cls = rt.fbuf("cls_norm_last" if last else "cls_norm", (Bf, C))
+                    rt.layernorm(tok.view(Bf, N, C)[:, 0].contiguous(), Bf, C, self.nw, self.nb, 1e-6, out_f=cls)
+                    if last:
+                        self.cls_last = cls
+                    else:
+                        readout.apply(j, raw, cls, Bf, P, t)
                 outs.append(t)
         return outs, last_f32, (ph, pw)
+
+
+# =============================================================================================
+class ReadoutEngine:
+    """use_clstoken (dpt.py:81-88,119-123): tap' = GELU(Linear_2C->C(cat(tap, cls expanded))). The cls half of the weight
+    acts on ONE row per frame, so it becomes a per-frame bias: c_b = W[:, C:] cls_b + bias, tap'_b = GELU(tap_b W[:, :C]^T + c_b)
+    — one small GEMM for the biases and one GEMM per frame. No shipped configuration enables the flag; this path is
+    about the constructor contract, not speed."""
+
+    def __init__(self, rt: Runtime, mods, C: int):
+        self.rt, self.C = rt, C
+        h = rt.prec
+        self.w1 = [pack.linear(m[0].weight[:, :C].contiguous(), h) for m in mods]
+        self.w2 = [pack.linear(m[0].weight[:, C:].contiguous(), h) for m in mods]
+        self.b = [pack.f32(m[0].bias) for m in mods]
+
+    def apply(self, j: int, x, cls_f32: torch.Tensor, Bf: int, P: int, out):
+        rt, C = self.rt, self.C
+        cb = rt.fbuf("ro_cb", (Bf, C))
+        rt.gemm(rt.to_half(cls_f32), self.w2[j], Bf, C, C, bias=self.b[j], out=cb)
+        for b in range(Bf):
+            rt.gemm(x.narrow0(b * P, P), self.w1[j], P, C, C, bias=cb[b], act=GELU, out=out.narrow0(b * P, P))
+        return out
 
 
 # =============================================================================================
@@ -252,9 +289,18 @@ class DPTEngine:
         s = mod.scratch
         self.rn = [pack.conv3x3(getattr(s, f"layer{i + 1}_rn").weight, h) for i in range(4)]
 
+        def fold(conv, bn):
+            """use_bn (util/blocks.py:49-51,71-77): eval-mode BatchNorm is a per-channel affine map, folded into the conv"""
+            w, b = conv.weight.detach().float(), conv.bias.detach().float()
+            if bn is None:
+                return w, b
+            sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + 1e-5)
+            return w * sc[:, None, None, None], (b - bn.running_mean.detach().float()) * sc + bn.bias.detach().float()
+
         def rcu(r):
-            return dict(w1=pack.conv3x3(r.conv1.weight, h), b1=pack.f32(r.conv1.bias),
-                        w2=pack.conv3x3(r.conv2.weight, h), b2=pack.f32(r.conv2.bias))
+            w1, b1 = fold(r.conv1, getattr(r, "bn1", None))
+            w2, b2 = fold(r.conv2, getattr(r, "bn2", None))
+            return dict(w1=pack.conv3x3(w1, h), b1=pack.f32(b1), w2=pack.conv3x3(w2, h), b2=pack.f32(b2))
 
         self.ref = {}
         for i in range(1, 5):

@@ -59,6 +59,18 @@ class Norm(nn.Module):
         self.bias = _param(c)
 
 
+class BatchNorm(nn.Module):
+    """nn.BatchNorm2d's parameters and buffers (the use_bn head): folded into the preceding convolution at engine build."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = _param(c)
+        self.bias = _param(c)
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
 class Gamma(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -94,24 +106,29 @@ def dinov2(encoder: str) -> nn.Module:
     return m
 
 
-def _rcu(f):
+def _rcu(f, bn=False):
     r = Holder()
     r.conv1 = Conv(f, f, 3)
     r.conv2 = Conv(f, f, 3)
+    if bn:  # util/blocks.py:49-51
+        r.bn1 = BatchNorm(f)
+        r.bn2 = BatchNorm(f)
     return r
 
 
-def _fusion(f):
+def _fusion(f, bn=False):
     b = Holder()
     b.out_conv = Conv(f, f, 1)
-    b.resConfUnit1 = _rcu(f)
-    b.resConfUnit2 = _rcu(f)
+    b.resConfUnit1 = _rcu(f, bn)
+    b.resConfUnit2 = _rcu(f, bn)
     return b
 
 
-def dpt_head(in_channels: int, features: int, out_channels) -> nn.Module:
+def dpt_head(in_channels: int, features: int, out_channels, use_bn: bool = False, use_clstoken: bool = False) -> nn.Module:
     h = Holder()
     h.projects = nn.ModuleList([Conv(in_channels, oc, 1) for oc in out_channels])
+    if use_clstoken:  # dpt.py:81-88: Linear(2C -> C) + GELU per tap
+        h.readout_projects = nn.ModuleList([nn.Sequential(Lin(2 * in_channels, in_channels), nn.Identity()) for _ in out_channels])
     h.resize_layers = nn.ModuleList([
         Conv(out_channels[0], out_channels[0], 4, transpose=True),
         Conv(out_channels[1], out_channels[1], 2, transpose=True),
@@ -122,7 +139,7 @@ def dpt_head(in_channels: int, features: int, out_channels) -> nn.Module:
     for i in range(4):
         setattr(s, f"layer{i + 1}_rn", Conv(out_channels[i], features, 3, bias=False))
     for i in range(1, 5):
-        setattr(s, f"refinenet{i}", _fusion(features))
+        setattr(s, f"refinenet{i}", _fusion(features, use_bn))
     s.output_conv1 = Conv(features, features // 2, 3)
     s.output_conv2 = nn.Sequential(Conv(features // 2, 32, 3), nn.Identity(), Conv(32, 1, 1), nn.Identity(), nn.Identity())
     h.scratch = s
@@ -161,8 +178,8 @@ def temporal_module(c: int, max_len: int) -> nn.Module:
     return t
 
 
-def dpt_head_temporal(in_channels, features, out_channels, num_frames) -> nn.Module:
-    h = dpt_head(in_channels, features, out_channels)
+def dpt_head_temporal(in_channels, features, out_channels, num_frames, use_bn: bool = False, use_clstoken: bool = False) -> nn.Module:
+    h = dpt_head(in_channels, features, out_channels, use_bn, use_clstoken)
     h.motion_modules = nn.ModuleList([
         temporal_module(out_channels[2], num_frames), temporal_module(out_channels[3], num_frames),
         temporal_module(features, num_frames), temporal_module(features, num_frames)])

@@ -126,7 +126,7 @@ def _scale_rules(key: str, shape: Tuple[int, ...], z):
         if ".fuser." in key:  # CXBlock layer scale (reference init 1e-6 would hide the block)
             return 0.5 + 0.1 * z
         return 1.0 + 0.1 * z  # ls1/ls2 (reference init_values=1.0)
-    is_norm = bool(re.search(r"(^|\.)(norm\d*|norms\.\d+|ff_norm|encoder\.1)\.(weight|bias)$", key))
+    is_norm = bool(re.search(r"(^|\.)(norm\d*|norms\.\d+|ff_norm|encoder\.1|bn\d)\.(weight|bias)$", key))
     if is_norm:
         return 1.0 + 0.1 * z if leaf == "weight" else 0.05 * z
     if leaf == "bias":
@@ -155,6 +155,20 @@ def _scale_rules(key: str, shape: Tuple[int, ...], z):
 def synth_param(seed: int, key: str, shape: Tuple[int, ...]) -> np.ndarray:
     shape = tuple(int(s) for s in shape)
     return np.asarray(_scale_rules(key, shape, normal(seed, key, shape)), dtype=np.float32)
+
+
+def synth_buffer(seed: int, key: str, shape: Tuple[int, ...]):
+    """Deterministic values for the BatchNorm buffers of the use_bn head (every other buffer keeps its module-computed
+    value): non-trivial running statistics, so that folding them into the convolution is really exercised."""
+    shape = tuple(int(s) for s in shape)
+    leaf = key.split(".")[-1]
+    if leaf == "running_mean":
+        return np.asarray(0.2 * normal(seed, key, shape), dtype=np.float32)
+    if leaf == "running_var":
+        return np.asarray(0.6 + 0.5 * np.abs(normal(seed, key, shape)), dtype=np.float32)
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, dtype=np.int64)
+    return None
 
 
 def fast_state_dict(named_shapes, seed: int = 1234):

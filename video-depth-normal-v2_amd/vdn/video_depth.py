@@ -6,7 +6,7 @@ import torch
 
 from . import modules, util
 from .depth_anything_v2 import _EngineOwner
-from .engine import DPTEngine, EncoderEngine
+from .engine import DPTEngine, EncoderEngine, ReadoutEngine
 
 INFER_LEN, OVERLAP, KEYFRAMES, INTERP_LEN = util.INFER_LEN, util.OVERLAP, util.KEYFRAMES, util.INTERP_LEN
 
@@ -15,15 +15,15 @@ class VideoDepthAnything(_EngineOwner):
     def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False,
                  use_clstoken=False, num_frames=32, pe="ape"):
         super().__init__()
-        if use_bn or use_clstoken or pe != "ape":
-            raise NotImplementedError("only the configuration the reference ships (no bn/clstoken, pe='ape')")
+        if pe != "ape":
+            raise NotImplementedError("pe='rope' is not enabled by any configuration the reference ships")
         if encoder not in ("vits", "vitl"):
             raise KeyError(encoder)  # video_depth.py:48-51
         self.intermediate_layer_idx = {"vits": [2, 5, 8, 11], "vitl": [4, 11, 17, 23]}
         self.encoder = encoder
         cfg = modules.ENCODERS[encoder]
         self.pretrained = modules.dinov2(encoder)
-        self.head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames)
+        self.head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames, use_bn, use_clstoken)
         self._features, self._out_channels = features, list(out_channels)
 
     def _engines(self):
@@ -32,6 +32,8 @@ class VideoDepthAnything(_EngineOwner):
             cfg = modules.ENCODERS[self.encoder]
             self._eng = dict(rt=rt, enc=EncoderEngine(rt, self.pretrained, cfg),
                              head=DPTEngine(rt, self.head, cfg["dim"], self._features, self._out_channels, temporal=True))
+            if hasattr(self.head, "readout_projects"):   # use_clstoken: per-frame, so it is applied to every tap right after the encoder
+                self._eng["enc"].readout = ReadoutEngine(rt, self.head.readout_projects, cfg["dim"])
         return self._eng
 
     @torch.no_grad()
