@@ -30,13 +30,14 @@ typedef void* vdn_stream; /* hipStream_t */
 
 enum vdn_status { VDN_OK = 0, VDN_EINVAL = -1, VDN_EUNSUPPORTED = -2, VDN_EALIGN = -3 };
 enum vdn_dtype { VDN_F16 = 0, VDN_BF16 = 1, VDN_F32 = 2, VDN_NONE = 3 };
-enum vdn_act { VDN_ACT_NONE = 0, VDN_ACT_GELU = 1, VDN_ACT_RELU = 2 };
+enum vdn_act { VDN_ACT_NONE = 0, VDN_ACT_GELU = 1, VDN_ACT_RELU = 2,
+               VDN_ACT_SILU = 3 /* only as the gate of VDN_ST_GEGLU: out = h * silu(gate) (SwiGLU, dinov2_layers/swiglu_ffn.py:29-33) */ };
 enum vdn_amode { VDN_A_PLAIN = 0, VDN_A_CONV3X3 = 1 };
 enum vdn_store {
   VDN_ST_PLAIN = 0,   /* out[row(m) * ldc + n]                                                   */
   VDN_ST_HEADS = 1,   /* n -> (split, head, e<64); per-split buffer, token- or dim-major          */
   VDN_ST_CONVT = 2,   /* ConvTranspose2d with kernel == stride: pixel-shuffle scatter to NHWC      */
-  VDN_ST_GEGLU = 3    /* weight rows packed as 16-row blocks [h | gate]; out = h * gelu(gate)      */
+  VDN_ST_GEGLU = 3    /* weight rows packed as 16-row blocks [h | gate]; out = h * gelu(gate), or h * silu(gate) with act = VDN_ACT_SILU */
 };
 
 /* One descriptor drives every GEMM-shaped op on the path:

@@ -22,7 +22,10 @@ def synth_sd(which: str, enc: str):
     from vdn import synth
     from oracle import ref_cpu as O
     sch = schema(which, enc)
-    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict([(k, tuple(s)) for k, s in sch["params"]], SEED).items()}
+    if enc == "vitg":   # 1.1 G parameters: torch's CPU generator (same torch build as the fixture generator), not the portable hash
+        sd = dict(synth.fast_state_dict([(k, tuple(s)) for k, s in sch["params"]], SEED))
+    else:
+        sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict([(k, tuple(s)) for k, s in sch["params"]], SEED).items()}
     for k, s in sch["buffers"]:
         b = synth.synth_buffer(SEED, k, tuple(s))   # BatchNorm statistics of the use_bn head ("Af" / "Bf" schemas)
         sd[k] = torch.from_numpy(np.asarray(b)) if b is not None else O.temporal_pe(s[-1], s[1])

@@ -70,6 +70,12 @@ def test_A_vitl_518_stream_fill_and_evict():
     _stream_A("A_vitl_518", "vitl", oracle_steps=1)
 
 
+def test_A_vitg_266_stream():
+    """ViT-g (run_video.py:32): 40 blocks of 24 heads with the SwiGLU FFN (gated epilogue with a SiLU gate, halves swapped at
+    packing), DPT features 384 / out_channels 1536: two frames on one memory bank against the reference fixture."""
+    _stream_A("A_vitg_266", "vitg", oracle_steps=1)
+
+
 def test_A_use_bn_and_use_clstoken():
     """DepthAnythingV2(use_bn=True, use_clstoken=True): BatchNorm (non-trivial running statistics) folded into the fusion
     blocks' convolutions, cls-token readout on taps 0-2 after the encoder and on the memory block's output for tap 3

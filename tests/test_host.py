@@ -90,7 +90,8 @@ def test_gemm_argument_validation_without_gpu():
     assert _abi.lib.vdn_gemm(ctypes.byref(d), None) == -2
 
 
-@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitb"), ("A", "vitl"), ("B", "vits"), ("B", "vitl"), ("Af", "vits"), ("Bf", "vits")])
+@pytest.mark.parametrize("which,enc", [("A", "vits"), ("A", "vitb"), ("A", "vitl"), ("A", "vitg"), ("B", "vits"), ("B", "vitl"), ("Af", "vits"),
+                                       ("Bf", "vits")])
 def test_state_dict_schema_matches_reference(which, enc):
     """Drop-in contract: same parameter/buffer keys and shapes as the reference classes; "Af" / "Bf" = the
     same classes built with use_bn=True, use_clstoken=True (BatchNorm parameters and buffers, readout_projects)."""

@@ -73,6 +73,11 @@ def _run_B(name, enc, which="B"):
     assert np.allclose(means, g["pre_stats_all"][:, 0], rtol=1e-3, atol=1e-4)
 
 
+def test_oracle_A_vitg_swiglu():
+    """ViT-g (run_video.py:32): 40 blocks, 24 heads, SwiGLU FFN (dinov2_layers/swiglu_ffn.py), DPT features 384."""
+    _run_A("A_vitg_266", "vitg")
+
+
 def test_oracle_use_bn_and_use_clstoken():
     """The two constructor flags no shipped configuration enables (dpt.py:81-88,119-123; util/blocks.py:49-51,71-77):
     fixtures from the imported reference built with use_bn=True, use_clstoken=True and non-trivial BatchNorm statistics."""

@@ -65,13 +65,18 @@ def install_shims():
     sys.path.insert(0, REF)
 
 
-def load_synth(model: torch.nn.Module):
+def load_synth(model: torch.nn.Module, fast: bool = False):
+    """fast: torch's CPU generator instead of the portable counter hash (ViT-g has 1.1 G parameters: minutes vs seconds);
+    the same torch build runs here and on the GPU box, tests/common.synth_sd takes the same branch for "vitg"."""
     from vdn import synth
     sd = model.state_dict()
     shapes = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
-    new = synth.synth_state_dict(shapes, SEED)
-    for k, v in new.items():
-        sd[k] = torch.from_numpy(v)
+    if fast:
+        sd.update(synth.fast_state_dict(shapes, SEED))
+    else:
+        new = synth.synth_state_dict(shapes, SEED)
+        for k, v in new.items():
+            sd[k] = torch.from_numpy(v)
     for k, v in model.named_buffers():   # BatchNorm statistics of the use_bn head: non-trivial, deterministic
         b = synth.synth_buffer(SEED, k, tuple(v.shape))
         if b is not None:
@@ -133,7 +138,7 @@ def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, na
     cfg = dict(O.MODEL_CONFIGS[enc], **(flags or {}))
     torch.manual_seed(0)
     model = DepthAnythingV2(**cfg).eval()
-    sd, shapes = load_synth(model)
+    sd, shapes = load_synth(model, fast=(enc == "vitg"))
     with open(os.path.join(GOLD, f"schema_A{'f' if flags else ''}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
@@ -414,6 +419,8 @@ JOBS = {
     # ViT-B (never tested before) + the stage fixtures G2 / G4 of SURVEY.md §8c
     "A_vitb_266": lambda: gen_A("vitb", 266, 266, 1, 3, [0, 1, 2], 1, "A_vitb_266", stages=True),
     "G_vits_392": lambda: gen_A("vits", 392, 392, 1, 2, [0, 1], 2, "G_vits_392", stages=True),
+    # ViT-g (run_video.py:32: SwiGLU FFN, 40 blocks, 24 heads, DPT features 384)
+    "A_vitg_266": lambda: gen_A("vitg", 266, 266, 1, 2, [0, 1], 1, "A_vitg_266"),
     # the two constructor flags no shipped configuration enables: BatchNorm in the fusion blocks, cls-token readout
     "Af_vits_266": lambda: gen_A("vits", 266, 266, 1, 3, [0, 1, 2], 1, "Af_vits_266", flags=dict(use_bn=True, use_clstoken=True)),
     "Bf_vits_266": lambda: gen_B("vits", 266, 266, 4, [0, 3], 1, "Bf_vits_266", flags=dict(use_bn=True, use_clstoken=True)),

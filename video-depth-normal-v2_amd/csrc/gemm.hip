@@ -84,7 +84,7 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
       if ((d.ldc & 3) || ((uintptr_t)d.out & 15)) return VDN_EALIGN;
       break;
     case VDN_ST_GEGLU:
-      if (!d.out || (d.N & 31) || d.ldc < d.N / 2 || d.act || d.gamma || d.res1 || d.res2 || d.tab || d.rowadd)
+      if (!d.out || (d.N & 31) || d.ldc < d.N / 2 || (d.act && d.act != VDN_ACT_SILU) || d.gamma || d.res1 || d.res2 || d.tab || d.rowadd)
         return VDN_EINVAL;
       if ((d.ldc & 3) || ((uintptr_t)d.out & 15)) return VDN_EALIGN;
       break;

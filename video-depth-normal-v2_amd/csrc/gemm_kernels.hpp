@@ -241,7 +241,12 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     if ((n & 16) || n + 16 >= p.N) return;
     a += bias_a;
     b += bias_b;
-    a = a * gelu4(b);
+    if (p.act == VDN_ACT_SILU) {  // SwiGLU (ViT-g FFN): gate * sigmoid(gate), sigmoid through one exp2 and one reciprocal
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= b[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * b[e]));
+    } else {
+      a = a * gelu4(b);
+    }
     const size_t o = (size_t)m * p.ldc + ((n >> 5) << 4) + (n & 15);
     if (p.out_dt == VDN_F32) {
       *(f32x4*)((float*)p.out + o) = a;

@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("VDN_LIB") or os.path.join(PKG, "lib", "libvdn_hip.so")
 
 F16, BF16, F32, NONE = 0, 1, 2, 3
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 A_PLAIN, A_CONV3X3 = 0, 1
 ST_PLAIN, ST_HEADS, ST_CONVT, ST_GEGLU = 0, 1, 2, 3
 PACK_LINEAR, PACK_CONV3X3, PACK_CONV3X3_TAPS, PACK_CONVT, PACK_GEGLU, PACK_ROPE = 0, 1, 2, 3, 4, 5

@@ -36,16 +36,26 @@ class EncoderEngine:
         self.cls = pack.f32(mod.cls_token).reshape(-1)
         self.pos = pack.f32(mod.pos_embed).reshape(-1, self.C)  # [1+37*37, C]
         self.blocks = []
+        self.hidden = cfg.get("swiglu") or 4 * self.C   # FFN width: Mlp 4C, or the SwiGLU hidden size of ViT-g
         for b in mod.blocks:
-            self.blocks.append(dict(
+            blk = dict(
                 n1w=pack.f32(b.norm1.weight), n1b=pack.f32(b.norm1.bias),
                 wqkv=pack.linear(b.attn.qkv.weight, h), bqkv=pack.f32(b.attn.qkv.bias),
                 wproj=pack.linear(b.attn.proj.weight, h), bproj=pack.f32(b.attn.proj.bias),
                 ls1=pack.f32(b.ls1.gamma),
                 n2w=pack.f32(b.norm2.weight), n2b=pack.f32(b.norm2.bias),
-                wfc1=pack.linear(b.mlp.fc1.weight, h), bfc1=pack.f32(b.mlp.fc1.bias),
-                wfc2=pack.linear(b.mlp.fc2.weight, h), bfc2=pack.f32(b.mlp.fc2.bias),
-                ls2=pack.f32(b.ls2.gamma)))
+                ls2=pack.f32(b.ls2.gamma))
+            if cfg.get("swiglu"):
+                # SwiGLU (swiglu_ffn.py:29-33): silu(x1) * x2 with [x1 ; x2] = w12 x. The gated epilogue computes
+                # h * act(gate) from rows packed [h ; gate], so the halves are swapped: h = x2, gate = x1, act = SiLU.
+                Hd = cfg["swiglu"]
+                w12, b12 = b.mlp.w12.weight, b.mlp.w12.bias
+                blk["wfc1"], blk["bfc1"] = pack.geglu(torch.cat([w12[Hd:], w12[:Hd]]), torch.cat([b12[Hd:], b12[:Hd]]), h)
+                blk["wfc2"], blk["bfc2"] = pack.linear(b.mlp.w3.weight, h), pack.f32(b.mlp.w3.bias)
+            else:
+                blk["wfc1"], blk["bfc1"] = pack.linear(b.mlp.fc1.weight, h), pack.f32(b.mlp.fc1.bias)
+                blk["wfc2"], blk["bfc2"] = pack.linear(b.mlp.fc2.weight, h), pack.f32(b.mlp.fc2.bias)
+            self.blocks.append(blk)
         self.nw, self.nb = pack.f32(mod.norm.weight), pack.f32(mod.norm.bias)
         self._pos_cache = {}
 
@@ -90,7 +100,8 @@ class EncoderEngine:
         q8, k8 = rt.qk8("enc_q8", Bf * Hh, npad), rt.qk8("enc_k8", Bf * Hh, npad)  # e5m2 planes for the score cross terms
         hn = rt.hbuf("enc_ln", (M, C))
         att = rt.hbuf("enc_att", (M, C))
-        f1 = rt.hbuf("enc_fc1", (M, 4 * C))
+        Hd = self.hidden
+        f1 = rt.hbuf("enc_fc1", (M, Hd))
         heads = dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
         outs, last_f32 = [], None
         readout = getattr(self, "readout", None)   # ReadoutEngine when the head was built with use_clstoken
@@ -103,8 +114,11 @@ class EncoderEngine:
             rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn", q8=q8, k8=k8)
             rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear")
             rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
-            rt.gemm(hn, b["wfc1"], M, 4 * C, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
-            rt.gemm(f1, b["wfc2"], M, C, 4 * C, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
+            if self.cfg.get("swiglu"):
+                rt.gemm(hn, b["wfc1"], M, 2 * Hd, C, bias=b["bfc1"], store=abi.ST_GEGLU, act=abi.ACT_SILU, out=f1, tag="enc_linear")
+            else:
+                rt.gemm(hn, b["wfc1"], M, Hd, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
+            rt.gemm(f1, b["wfc2"], M, C, Hd, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
             if probe is not None:
                 probe(i, tok)
             if i in self.taps:

@@ -16,11 +16,13 @@ ENCODERS = {  # depth_anything_v2/dinov2.py:339-378; taps depth_anything_v2.py:2
     "vits": dict(dim=384, depth=12, heads=6, taps=[2, 5, 8, 11]),
     "vitb": dict(dim=768, depth=12, heads=12, taps=[2, 5, 8, 11]),
     "vitl": dict(dim=1024, depth=24, heads=16, taps=[4, 11, 17, 23]),
+    "vitg": dict(dim=1536, depth=40, heads=24, taps=[9, 19, 29, 39], swiglu=4096),  # dinov2.py:381-395; FFN = SwiGLU, hidden (int(4C 2/3)+7)//8*8
 }
 MODEL_CONFIGS = {  # run_video.py:28-33
     "vits": {"encoder": "vits", "features": 64, "out_channels": [48, 96, 192, 384]},
     "vitb": {"encoder": "vitb", "features": 128, "out_channels": [96, 192, 384, 768]},
     "vitl": {"encoder": "vitl", "features": 256, "out_channels": [256, 512, 1024, 1024]},
+    "vitg": {"encoder": "vitg", "features": 384, "out_channels": [1536, 1536, 1536, 1536]},
 }
 
 
@@ -97,8 +99,12 @@ def dinov2(encoder: str) -> nn.Module:
         b.ls1 = Gamma(C)
         b.norm2 = Norm(C)
         b.mlp = Holder()
-        b.mlp.fc1 = Lin(C, 4 * C)
-        b.mlp.fc2 = Lin(4 * C, C)
+        if cfg.get("swiglu"):  # dinov2_layers/swiglu_ffn.py:13-33
+            b.mlp.w12 = Lin(C, 2 * cfg["swiglu"])
+            b.mlp.w3 = Lin(cfg["swiglu"], C)
+        else:
+            b.mlp.fc1 = Lin(C, 4 * C)
+            b.mlp.fc2 = Lin(4 * C, C)
         b.ls2 = Gamma(C)
         blocks.append(b)
     m.blocks = nn.ModuleList(blocks)
