@@ -390,7 +390,7 @@ def test_streaming_mode_against_reference_fixture():
     assert len(model._stream["cache"]) == 42
 
 
-@pytest.mark.parametrize("version,name", [(5, "R5_vits"), (4, "R4_vits")])
+@pytest.mark.parametrize("version,name", [(5, "R5_vits"), (4, "R4_vits"), (5, "R5f_vits")])
 def test_depth_refiner_v4_v5_against_reference_fixture(version, name):
     """the v4 / v5 wrappers (median radix select, scale, Sobel normals, temporal network, shift +
     residual) against the fixture written by the imported reference model; tolerance 1e-3 on the refined depth."""
@@ -400,8 +400,9 @@ def test_depth_refiner_v4_v5_against_reference_fixture(version, name):
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     v, S, H, W, seed = [int(t) for t in g["meta"]]
     cls = importlib.import_module(f"vdn.video_depth_model_v{version}").VideoDepthAnything
-    m = cls(**vdn.MODEL_CONFIGS["vits"])
-    m.load_state_dict(synth_sd(f"R{version}", "vits"), strict=True)
+    flagged = name.startswith(f"R{version}f")   # built with use_bn=True, use_clstoken=True
+    m = cls(**dict(vdn.MODEL_CONFIGS["vits"], **(dict(use_bn=True, use_clstoken=True) if flagged else {})))
+    m.load_state_dict(synth_sd(f"R{version}f" if flagged else f"R{version}", "vits"), strict=True)
     m = m.to("cuda").eval()
     x = torch.from_numpy(synth.depth_clip(seed, S, H, W))[None]
     out = m.forward(x.cuda())[0].cpu()

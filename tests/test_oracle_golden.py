@@ -123,7 +123,7 @@ def test_oracle_streaming_mode():
     assert len(st.frame_cache_list) == 42 and st.frame_id_list[0] == 0
 
 
-@pytest.mark.parametrize("version,name", [(5, "R5_vits"), (4, "R4_vits")])
+@pytest.mark.parametrize("version,name", [(5, "R5_vits"), (4, "R4_vits"), (5, "R5f_vits")])
 def test_oracle_depth_refiner_v4_v5(version, name):
     """models/video_depth_model_v{4,5}.VideoDepthAnything.forward: per-frame median scale,
     Sobel normals, encoder + temporal head, ReLU before the resize, scalar shift + residual."""
@@ -134,7 +134,8 @@ def test_oracle_depth_refiner_v4_v5(version, name):
     x = torch.from_numpy(synth.depth_clip(seed, S, H, W))[None]
     tr = {}
     with torch.no_grad():
-        out = O.depth_refiner_forward(synth_sd(f"R{version}", "vits"), x, "vits", version=version, trace=tr)
+        which = f"R{version}f" if name.startswith(f"R{version}f") else f"R{version}"   # "f": use_bn + use_clstoken
+        out = O.depth_refiner_forward(synth_sd(which, "vits"), x, "vits", version=version, trace=tr)
     assert rel_l2(tr["median"], g["median"]) < 1e-6 and rel_l2(tr["scale"], g["scale"]) < 1e-6
     assert rel_l2(tr["net_depth"][0], g["net_depth"]) < TOL
     assert rel_l2(out[0], g["out"]) < TOL

@@ -233,7 +233,7 @@ def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str, fla
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
-def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str, num_frames: int = 32, sub: int = 1):
+def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str, num_frames: int = 32, sub: int = 1, flags: dict = None):
     """models/video_depth_model_v{4,5}.VideoDepthAnything on a synthetic depth clip."""
     import importlib
     from vdn import synth
@@ -245,11 +245,11 @@ def gen_refiner(version: int, enc: str, S: int, H: int, W: int, name: str, num_f
                                                   os.path.join(REF, "models", f"video_depth_model_v{version}.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    cfg = O.MODEL_CONFIGS[enc]
+    cfg = dict(O.MODEL_CONFIGS[enc], **(flags or {}))
     torch.manual_seed(0)
     model = mod.VideoDepthAnything(num_frames=num_frames, **cfg).eval()
     sd, shapes = load_synth(model)
-    with open(os.path.join(GOLD, f"schema_R{version}_{enc}.json"), "w") as f:
+    with open(os.path.join(GOLD, f"schema_R{version}{'f' if flags else ''}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
     x = torch.from_numpy(synth.depth_clip(SEED, S, H, W))[None]
@@ -432,6 +432,7 @@ JOBS = {
     # BASELINE configs[4]: v5 refiner, ViT-L, num_frames = 64 on a [1, 64, 1024, 1024] clip (the network runs at 224 x 224)
     "R5_vitl_T64": lambda: gen_refiner(5, "vitl", 64, 1024, 1024, "R5_vitl_T64", num_frames=64, sub=16),
     "R5_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5_vits"),
+    "R5f_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5f_vits", flags=dict(use_bn=True, use_clstoken=True)),
     "R4_vits": lambda: gen_refiner(4, "vits", 3, 126, 168, "R4_vits"),
 }
 

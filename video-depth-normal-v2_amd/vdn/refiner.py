@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import modules
 from .depth_anything_v2 import _EngineOwner
-from .engine import DPTEngine, EncoderEngine
+from .engine import DPTEngine, EncoderEngine, ReadoutEngine
 
 
 class _DepthRefiner(_EngineOwner):
@@ -19,8 +19,8 @@ class _DepthRefiner(_EngineOwner):
     def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False, use_clstoken=False,
                  num_frames=32, max_depth=65535, pe="ape", use_residual=True, input_normal=True):
         super().__init__()
-        if use_bn or use_clstoken or pe != "ape":
-            raise NotImplementedError("only the configuration the reference ships (no bn/clstoken, pe='ape')")
+        if pe != "ape":
+            raise NotImplementedError("pe='rope' is not enabled by any configuration the reference ships")
         if encoder not in ("vits", "vitl"):
             raise KeyError(encoder)
         self.intermediate_layer_idx = {"vits": [2, 5, 8, 11], "vitl": [4, 11, 17, 23]}
@@ -30,7 +30,7 @@ class _DepthRefiner(_EngineOwner):
         self.pretrained = modules.dinov2(encoder)
         self.scale_head = modules.Holder()
         self.scale_head.feat = nn.Sequential(nn.Identity(), modules.Conv(1, 1, 1))  # quantile pool has no weights
-        self.temporal_head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames)
+        self.temporal_head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames, use_bn, use_clstoken)
         self.shift_head = nn.Sequential(modules.Conv(1, 1, 1))
         self._features, self._out_channels = features, list(out_channels)
 
@@ -43,6 +43,8 @@ class _DepthRefiner(_EngineOwner):
                              head=DPTEngine(rt, self.temporal_head, cfg["dim"], self._features, self._out_channels, temporal=True),
                              scale_wb=(float(sc.weight.reshape(()).item()), float(sc.bias.reshape(()).item())),
                              shift_wb=(float(sh.weight.reshape(()).item()), float(sh.bias.reshape(()).item())))
+            if hasattr(self.temporal_head, "readout_projects"):   # use_clstoken
+                self._eng["enc"].readout = ReadoutEngine(rt, self.temporal_head.readout_projects, cfg["dim"])
         return self._eng
 
     @torch.no_grad()
