@@ -118,6 +118,19 @@ def test_refiner_state_dict_schema_matches_reference(version):
     m.load_state_dict(m.state_dict(), strict=True)
 
 
+def test_reference_import_paths_exist():
+    """A reference user's imports, with the package name swapped: depth_anything_v2.depth_anything_v2, video_depth_anything.
+    video_depth, video_depth_anything.video_depth_stream, models.video_depth_model_v4 / _v5."""
+    import importlib
+    for mod, cls, methods in (("vdn.depth_anything_v2", "DepthAnythingV2", ["forward", "infer_image", "image2tensor", "clear_memory"]),
+                              ("vdn.video_depth", "VideoDepthAnything", ["forward", "infer_video_depth"]),
+                              ("vdn.video_depth_stream", "VideoDepthAnything", ["forward", "infer_video_depth_one"]),
+                              ("vdn.video_depth_model_v4", "VideoDepthAnything", ["forward"]),
+                              ("vdn.video_depth_model_v5", "VideoDepthAnything", ["forward"])):
+        c = getattr(importlib.import_module(mod), cls)
+        assert all(callable(getattr(c, m)) for m in methods), (mod, methods)
+
+
 def test_product_refuses_cpu():
     import vdn
     m = vdn.DepthAnythingV2(**vdn.MODEL_CONFIGS["vits"])
