@@ -700,11 +700,16 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
   else if (Ql && q8 && k8 && DT == VDN_F16) {
     if constexpr (DT == VDN_F16) {
+#ifndef VDN_ATTN2_NW
+#define VDN_ATTN2_NW 4
+#endif
+      constexpr int NW = VDN_ATTN2_NW;
+      const dim3 grid2(((nq + 32 * NW - 1) / (32 * NW)) * B * H);
       if (attn_stream() == 2 && pv_products() == 1)
-        hipLaunchKernelGGL(flash_attn2_kernel<1>, grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
+        hipLaunchKernelGGL((flash_attn2_kernel<1, NW>), grid2, dim3(64 * NW), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
                            (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
       else if (attn_stream() == 2)
-        hipLaunchKernelGGL(flash_attn2_kernel<2>, grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
+        hipLaunchKernelGGL((flash_attn2_kernel<2, NW>), grid2, dim3(64 * NW), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
                            (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
       else
       hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,

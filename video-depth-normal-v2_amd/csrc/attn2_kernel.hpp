@@ -17,8 +17,12 @@
 
 // PV: MFMA products per P V term: 2 = P~ (V_hi + V_lo), 1 = P~ V_hi with V_hi rounded to nearest by the producer
 // (vdn_gemm rounds the hi plane of transposed head splits that way): 8 MFMAs, 8 fragment reads and 2 LDS-DMA pieces fewer per tile.
-template <int PV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn2_kernel(
+// NW: waves per workgroup (32 queries each). 4 (shipped): two workgroups per CU, every wave issues 2 LDS-DMA pieces per tile
+// and plane. 8 (A/B build -DVDN_ATTN2_NW=8): one workgroup per CU, one piece per wave — the same 2 waves per SIMD and half the
+// DMA instructions per wave (an LDS-DMA piece costs its wave 60-180 cycles of issue: s_memtime stamps put ~500 of a tile's
+// 3000 cycles there), but one barrier over 8 waves instead of two independent 4-wave groups: measured 134 vs 125 us. Stays 4.
+template <int PV, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn2_kernel(
     const _Float16* __restrict__ Q, const _Float16* __restrict__ K, const _Float16* __restrict__ Vt, _Float16* __restrict__ out,
     const _Float16* __restrict__ Kl, const _Float16* __restrict__ Vtl, _Float16* __restrict__ outl, const uint8_t* __restrict__ Q8,
     const uint8_t* __restrict__ K8, int H, int nq, int nq_pad, int nk, int nk_pad, float scale_log2) {
@@ -31,10 +35,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (nq + 127) >> 7;
+  constexpr int QB = 32 * NW;      // queries per workgroup
+  constexpr int NPC = 8 / NW;      // LDS-DMA pieces (of the 8 of a 64-row tile plane) per wave
+  const int nqb = (nq + QB - 1) / QB;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);  // the q-blocks of one (batch, head) share an XCD's L2
   const int bh = logical / nqb;
-  const int q0 = (logical - bh * nqb) * 128 + wave * 32;
+  const int q0 = (logical - bh * nqb) * QB + wave * 32;
   const int r = lane & 31, h = lane >> 5;
 
   // ---- Q fragments (B operands): fp16 Q[q][16 ks + 8 h + j] and the two 8-bit planes Q8[q][32 h + j]
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __amdgpu_buffer_rsrc_t rK = rsrc(K), rV = rsrc(Vt), rK8 = rsrc(K8), rVl = rsrc(Vtl);
   int koff[2], voff[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NPC; ++i) {
     const int row = (wave + 4 * i) * 8 + lr;
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     koff[i] = (row * 64 + c * 8) * (int)sizeof(T);
@@ -201,10 +207,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto vlr = [&]() { l_run = l_run * alpha + (ls0 + ls1); A2_PIN(l_run); };
     auto dma = [&](auto ic) {  // the iteration's 8 LDS-DMA pieces of this wave: V_t (4), K_{t+2} (4)
       constexpr int i = decltype(ic)::value;
-      if constexpr (i < 4) {
-        if constexpr (PV == 2 || !(i & 1)) stage_v_piece(PAR, t, i >> 1, i & 1);
+      if constexpr (((i & 3) >> 1) < NPC) {   // piece index (i >> 1) & 1: a wave of an 8-wave workgroup owns one piece per plane
+        if constexpr (i < 4) {
+          if constexpr (PV == 2 || !(i & 1)) stage_v_piece(PAR, t, i >> 1, i & 1);
+        } else if constexpr (HAS_NEXT) {
+          stage_k_piece(PAR, tk, (i - 4) >> 1, i & 1);
+        }
       }
-      else if constexpr (HAS_NEXT) stage_k_piece(PAR, tk, (i - 4) >> 1, i & 1);
     };
 #if VDN_ATTN_ABL & 16  // timing ablations (attn.hip): no fragment reads / no MFMA / no softmax VALU / no LDS-DMA
 #define A2_LDV(c, db, w, b) A2_PIN(fr[b]);
@@ -249,7 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define A2_FENCE() __builtin_amdgcn_sched_barrier(0);
 #if VDN_ATTN_ABL & 64  // timing build: cycles of the four quarters of the stream (and of the iteration's tail) summed per wave
 #define A2_STAMP(i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (i > 0) stamp_sum[i - 1] += now - stamp_last; stamp_last = now; }
-#include "attn2_stream_stamps.inc"
+#ifndef VDN_ATTN2_STAMPS_INC   // the stamped twin of the stream of the PV mode being timed (tools/gen_attn_stream.py --stamps [--pv 1])
+#define VDN_ATTN2_STAMPS_INC "attn2_stream_stamps.inc"
+#endif
+#include VDN_ATTN2_STAMPS_INC
 #undef A2_STAMP
 #else
 #ifndef VDN_ATTN2_INC
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- prologue: K_0 (and K_1) in flight, S(0) from buffer 0
   auto stage_k_all = [&](int buf, int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { stage_k_piece(buf, t, i, false); stage_k_piece(buf, t, i, true); }
+    for (int i = 0; i < NPC; ++i) { stage_k_piece(buf, t, i, false); stage_k_piece(buf, t, i, true); }
   };
   stage_k_all(0, 0);
   if (nt > 1) stage_k_all(1, 1);
