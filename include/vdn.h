@@ -106,7 +106,8 @@ typedef struct vdn_gemm_desc {
    *     A_hi*W_hi  +  A_hi*W_lo (if W_lo)  +  A_lo*W_hi (if A_lo)
    * as extra K segments of the same MFMA loop (fp32-faithful to ~2^-21 instead of 2^-11), and
    * half outputs are written as (hi = round-toward-zero, lo = remainder) when out_lo / dst_lo is
-   * given. hi and lo share their sign, so relu_a acts on each plane independently.              */
+   * given. hi and lo share their sign, so relu_a acts on each plane independently. TRANSPOSED head splits (V^T) are the
+   * exception: hi is rounded to nearest, and their dst_lo may be NULL on its own (the one-product P V attention reads hi only). */
   const void* A_lo;
   const void* W_lo;
   void* out_lo;

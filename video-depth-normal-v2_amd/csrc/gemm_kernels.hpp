@@ -87,7 +87,7 @@ __host__ __device__ inline int epi_flavour(const vdn_gemm_desc& d) {
     return VDN_STX_RES;
   if (d.store == VDN_ST_HEADS && !d.rope[0] && !d.rope[1] && !d.rope[2] && d.nsplit >= 1) {
     for (int i = 0; i < d.nsplit; ++i)
-      if (!d.dst[i] || !d.dst_lo[i]) return d.store;
+      if (!d.dst[i] || (!d.dst_lo[i] && !d.transposed[i])) return d.store;   // a transposed split (V^T) may come without a lo plane
     return VDN_STX_HEADS;
   }
   return d.store;

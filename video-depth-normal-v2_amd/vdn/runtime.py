@@ -110,6 +110,15 @@ class Runtime:
             return None
         return self.buf(name, (bh, tpad, 128), torch.uint8, zero=True)
 
+    def v_dst(self, vt: HL) -> HL:
+        """Destination planes of a V^T head split: when the attention in use is the one-product P V kernel (fp16 split planes
+        with the 8-bit Q / K planes, vdn_flash_attn_set_pv_products(1), generated stream) nothing ever reads V^T's lo plane,
+        so the projection does not write it — 2-byte scattered stores: 218 -> 210 us on the batch-8 QKV GEMM."""
+        if (vt.lo is not None and self.half == torch.float16 and os.environ.get("VDN_ATTN_QK8", "1") != "0"
+                and abi.lib.vdn_flash_attn_get_pv_products() == 1 and abi.lib.vdn_flash_attn_get_stream() == 2):
+            return HL(vt.hi, None)
+        return vt
+
     def fbuf(self, name, shape, zero=False):
         return self.buf(name, shape, torch.float32, zero)
 
