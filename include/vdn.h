@@ -132,7 +132,7 @@ typedef struct vdn_gemm_desc {
   /* HEADS, split-plane mode, VDN_F16 only: optional 8-bit planes of a token-major split s (Q / K) for the attention
    * kernel's cross terms (vdn_flash_attn Q8 / K8): u8 [Bt, heads, tpad, 128], per token 64 bytes of e5m2(v) followed by
    * 64 bytes of e5m2((v - hi(v)) * 2^10), same token mapping as dst[s]. NULL = not written. Must be NULL for
-   * transposed splits.                                                                                            */
+   * transposed splits. A split with 8-bit planes may leave its dst_lo NULL (the attention then never reads the fp16 lo plane).                                                                                            */
   void* dst8[3];
   /* 8-bit cross-term planes of the GEMM operands themselves (plain A, VDN_F16, K % 64 == 0; all three optional):
    * A8 u8 [2, M, K] and W8 u8 [2, N, ldb]: plane 0 = e5m2(v), plane 1 = e5m2((v - hi(v)) * 2^10), same row-major shape

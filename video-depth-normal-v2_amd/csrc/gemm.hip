@@ -102,7 +102,7 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
       for (int i = 0; i < d.nsplit; ++i) {
         if (!d.dst[i] || ((uintptr_t)d.dst[i] & 15)) return VDN_EINVAL;
         if (d.rope[i] && (!d.rope_cs || d.rope_mod <= 0)) return VDN_EINVAL;
-        if (d.dst8[i] && (d.transposed[i] || !d.dst_lo[i] || d.dt != VDN_F16 || ((uintptr_t)d.dst8[i] & 15))) return VDN_EINVAL;
+        if (d.dst8[i] && (d.transposed[i] || !d.W_lo || d.dt != VDN_F16 || ((uintptr_t)d.dst8[i] & 15))) return VDN_EINVAL;
       }
       break;
     default:

@@ -87,7 +87,7 @@ __host__ __device__ inline int epi_flavour(const vdn_gemm_desc& d) {
     return VDN_STX_RES;
   if (d.store == VDN_ST_HEADS && !d.rope[0] && !d.rope[1] && !d.rope[2] && d.nsplit >= 1) {
     for (int i = 0; i < d.nsplit; ++i)
-      if (!d.dst[i] || (!d.dst_lo[i] && !d.transposed[i])) return d.store;   // a transposed split (V^T) may come without a lo plane
+      if (!d.dst[i] || (!d.dst_lo[i] && !d.transposed[i] && !d.dst8[i])) return d.store;   // V^T, and Q / K with 8-bit planes, may come without lo
     return VDN_STX_HEADS;
   }
   return d.store;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     } else {
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
       *(typename H::V4*)(dst + o) = h;
-      *(typename H::V4*)(dlo + o) = l;
+      if (dlo) *(typename H::V4*)(dlo + o) = l;   // with 8-bit planes the fp16 lo plane is optional: the attention reads e5m2(lo 2^10) instead
       if (p.dst8[split]) {
         uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + e0;
         const float k = VDN_LO8_SCALE;
@@ -288,14 +288,15 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
       } else {
         const size_t o = (hb * p.tpad + tk) * 64 + 2 * pi;
         typename H::V8 h8, l8;
+        const bool sp = dlo || p.dst8[split];   // split planes: hi toward zero + remainder (fp16 plane and / or the 8-bit one)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          if (dlo) { T x0, x1; split_rtz(o8[e], x0, x1); h8[e] = x0; l8[e] = x1; }
+          if (sp) { T x0, x1; split_rtz(o8[e], x0, x1); h8[e] = x0; l8[e] = x1; }
           else h8[e] = (T)o8[e];
         }
         *(typename H::V8*)(dst + o) = h8;
         if (dlo) *(typename H::V8*)(dlo + o) = l8;
-        if (dlo && p.dst8[split]) {
+        if (p.dst8[split]) {
           uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + 2 * pi;
           const float k = VDN_LO8_SCALE;
           *(u32x2*)d8 = u32x2{pk4_bf8(o8[0], o8[1], o8[2], o8[3]), pk4_bf8(o8[4], o8[5], o8[6], o8[7])};
@@ -311,14 +312,15 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     } else {
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
       typename H::V4 h, l;
+      const bool sp = dlo || p.dst8[split];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (dlo) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
+        if (sp) { T x0, x1; split_rtz(a[e], x0, x1); h[e] = x0; l[e] = x1; }
         else h[e] = (T)a[e];
       }
       *(typename H::V4*)(dst + o) = h;
       if (dlo) *(typename H::V4*)(dlo + o) = l;
-      if (dlo && p.dst8[split]) {
+      if (p.dst8[split]) {
         uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + e0;
         const float k = VDN_LO8_SCALE;
         *(uint32_t*)d8 = pk4_bf8(a[0], a[1], a[2], a[3]);
@@ -395,7 +397,7 @@ __device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x
     } else {
       const size_t o = (hb * p.tpad + tk) * 64 + e0;
       *(V8*)(dst + o) = h;
-      *(V8*)(dlo + o) = l;
+      if (dlo) *(V8*)(dlo + o) = l;
       if (p.dst8[split]) {  // e5m2 planes for the attention cross terms
         uint8_t* d8 = (uint8_t*)p.dst8[split] + (hb * p.tpad + tk) * 128 + e0;
         *(u32x2*)d8 = u32x2{pk4_bf8(a[0], a[1], a[2], a[3]), pk4_bf8(a[4], a[5], a[6], a[7])};

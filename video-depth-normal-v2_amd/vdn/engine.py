@@ -102,7 +102,7 @@ class EncoderEngine:
         att = rt.hbuf("enc_att", (M, C))
         Hd = self.hidden
         f1 = rt.hbuf("enc_fc1", (M, Hd))
-        heads = dict(dst=[q, k, rt.v_dst(vt)], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
+        heads = dict(dst=[rt.qk_dst(q, q8), rt.qk_dst(k, k8), rt.v_dst(vt)], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
         outs, last_f32 = [], None
         readout = getattr(self, "readout", None)   # ReadoutEngine when the head was built with use_clstoken
         probe = getattr(self, "probe", None)   # tests only: callable(block index, fp32 token stream [M, C]); -1 = input of block 0
@@ -565,13 +565,13 @@ class MemoryEngine:
             k8s = [rt.qk8(f"nomem_k8{l}", B * Hh, pp) for l in range(len(self.layers))]
             for l, L in enumerate(self.layers):
                 rt.gemm(a_nm, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
-                        heads=dict(dst=[ks[l], rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs,
+                        heads=dict(dst=[rt.qk_dst(ks[l], k8s[l]), rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs,
                                    rope_mod=P, heads=Hh, tokens=P, tpad=pp))
         else:
             nk, nk_pad = S * P, tp
-        sh = dict(dst=[q, k, rt.v_dst(vt)], dst8=[q8, k8, None], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
+        sh = dict(dst=[rt.qk_dst(q, q8), rt.qk_dst(k, k8), rt.v_dst(vt)], dst8=[q8, k8, None], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
                   tokens=P, tpad=pp)
-        qh = dict(dst=[q], dst8=[q8], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
+        qh = dict(dst=[rt.qk_dst(q, q8)], dst8=[q8], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
         for l, L in enumerate(self.layers):
             rt.layernorm(x, M, C, L["n1w"], L["n1b"], 1e-5, out_h=n)
             rt.gemm(n, L["wqkv"], M, 3 * C, C, bias=L["bqkv"], store=abi.ST_HEADS, heads=sh)
@@ -617,6 +617,6 @@ class MemoryEngine:
         cs = self._rope_for(int(math.sqrt(P)))
         for l, L in enumerate(self.layers):
             rt.gemm(feat, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
-                    heads=dict(dst=[ks[l], rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P,
+                    heads=dict(dst=[rt.qk_dst(ks[l], k8s[l]), rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P,
                                heads=Hh, tokens=P, tok_off=slot * P, tpad=tp))
         return feat

@@ -119,6 +119,11 @@ class Runtime:
             return HL(vt.hi, None)
         return vt
 
+    def qk_dst(self, t: HL, t8) -> HL:
+        """Destination planes of a Q / K head split: with the 8-bit planes (t8) the attention reads e5m2(lo 2^10) and never
+        the fp16 lo plane, so the projection does not write it."""
+        return HL(t.hi, None) if (t8 is not None and t.lo is not None) else t
+
     def fbuf(self, name, shape, zero=False):
         return self.buf(name, shape, torch.float32, zero)
 
