@@ -163,7 +163,7 @@ typedef struct vdn_gemm_tuning {
   int splitk_occ;   /* VDN_SPLITK_OCC    split K when the 128-row tile grid covers <= this percent of the CUs (50) */
   int splitk_max;   /* VDN_SPLITK_MAX    most K slices (8)                                                        */
   int min_tiles;    /* VDN_GEMM_MIN_TILES plain-A problems with fewer 128x256 tiles use the 4-wave 128x128 kernel (96) */
-  float f128, f192; /* VDN_GEMM_F128/F192 cost factors of the smaller M tiles in pick_bm (1.12, 1.2)              */
+  float f128, f192; /* VDN_GEMM_F128/F192 cost factors of the smaller M tiles in pick_bm (1.3, 1.2)               */
   int x8;           /* VDN_GEMM_X8       1 (default): launches that carry A8 / W8 planes use the 8-bit cross-term kernel (an experiment: slower than the 3-product kernel) */
 } vdn_gemm_tuning;
 int vdn_gemm_get_tuning(vdn_gemm_tuning* out);
