@@ -61,7 +61,7 @@ __device__ __forceinline__ void for_each_slot(F& f) {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // Timing ablations for tools/attn_ablate.sh variant builds only (results are wrong with any bit set; the shipped
-// library is built without the macro): 1 no LDS-DMA in the loop, 2 no workgroup barrier, 4 no softmax VALU, 8 no MFMA, 16 no fragment reads from LDS, 32 one workgroup per CU
+// library is built without the macro): 1 no LDS-DMA in the loop, 2 no workgroup barrier, 4 no softmax VALU, 8 no MFMA, 16 no fragment reads from LDS, 32 one workgroup per CU, 64 s_memtime stamps, 128 softmax without its fma
 // (96 KB of LDS requested: one wave per SIMD).
 #ifndef VDN_ATTN_ABL
 #define VDN_ATTN_ABL 0

@@ -185,8 +185,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     auto vf = [&](auto pc) {  // pair p: scores sc[p >> 3][2 (p & 7)], +1
       constexpr int p = decltype(pc)::value, kb = p >> 3, i = (p & 7) * 2;
-      ff[p & 1][0] = fmaf(sc[kb][i], scale_log2, mb);
-      ff[p & 1][1] = fmaf(sc[kb][i + 1], scale_log2, mb);
+      if constexpr (VDN_ATTN_ABL & 128) {  // timing ablation: what a pre-scaled Q + the maximum as accumulator init would save (no fma)
+        ff[p & 1][0] = sc[kb][i];
+        ff[p & 1][1] = sc[kb][i + 1];
+      } else {
+        ff[p & 1][0] = fmaf(sc[kb][i], scale_log2, mb);
+        ff[p & 1][1] = fmaf(sc[kb][i + 1], scale_log2, mb);
+      }
     };
     auto vx = [&](auto pc) {
       constexpr int p = decltype(pc)::value;
