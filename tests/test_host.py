@@ -181,7 +181,7 @@ def test_generated_attention_stream_is_current_and_well_formed(inc, args, n_mfma
     once with F_p before X_p before C_p, the row maximum / rescale test precede the first F, each LDS-DMA piece once."""
     import re
     import subprocess
-    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_stream.py"), "--dma-first-gap", "0", "--dma-stride", "1"] + args,
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_stream.py")] + args,
                          capture_output=True, text=True, check=True).stdout
     with open(os.path.join(ROOT, "video-depth-normal-v2_amd", "csrc", inc)) as f:
         assert f.read() == gen, f"{inc} is stale: regenerate with tools/gen_attn_stream.py"
