@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (2, 50, "[(0, 0, 1), (1, 1, 1), (2, 0, 2)]"),   # two whole windows, then one window frame-sharded over both ranks
     (4, 20, "[(0, 0, 4)]"),                         # one window, 8 frames per rank
     (3, 20, "[(0, 0, 2)]"),                         # rank 2 owns no head job (idle-rank path), still encodes its frames
+    (4, 130, "[(0, 0, 1), (1, 1, 1), (2, 2, 1), (3, 3, 1), (4, 0, 2), (5, 2, 2)]"),   # hybrid: 4 whole windows, then 2 windows on 2 ranks each
+    (4, 256, "[(0, 0, 1), (1, 0, 1), (2, 0, 1), (3, 1, 1), (4, 1, 1), (5, 1, 1), (6, 2, 1), (7, 2, 1), (8, 2, 1), (9, 3, 1), (10, 3, 1), (11, 3, 1)]"),   # configs[3]'s 12-window clip: contiguous runs of 3 windows per rank, tap exchange between neighbours
 ])
 def test_sharded_clip_equals_single_process_on_real_kernels(ranks, frames, schedule):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}

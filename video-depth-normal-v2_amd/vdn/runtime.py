@@ -122,6 +122,8 @@ class Runtime:
     def qk_dst(self, t: HL, t8) -> HL:
         """Destination planes of a Q / K head split: with the 8-bit planes (t8) the attention reads e5m2(lo 2^10) and never
         the fp16 lo plane, so the projection does not write it."""
+        if abi.lib.vdn_flash_attn_get_pv_products() == 3:
+            return t   # the 3-product P V kernel (flash_attn_kernel<.., false, false>) takes its score cross terms from the fp16 lo planes
         return HL(t.hi, None) if (t8 is not None and t.lo is not None) else t
 
     def fbuf(self, name, shape, zero=False):
