@@ -90,7 +90,7 @@ typedef struct vdn_gemm_desc {
    * with m -> (bt = m / tokens, t = m % tokens + tok_off).
    * rope[s] != 0 rotates adjacent pairs (2i,2i+1) of each head by rope_cs[(t % rope_mod), i]
    * = (cos, sin) (sam2/modeling/position_encoding.py:212-239); requires the weight rows of that
-   * split to be packed pair-split (see vdn_pack.h / vdn/pack.py).                                */
+   * split to be packed pair-split (VDN_PACK_ROPE of vdn_pack_weight below).                      */
   void* dst[3];
   int32_t nsplit, heads, tokens, tok_off, tpad;
   int32_t transposed[3];
@@ -139,11 +139,19 @@ typedef struct vdn_gemm_desc {
    * as the fp16 operand (lda == K). When both are given, the kernel accumulates A_hi W_hi^T on fp16 MFMAs and the two cross
    * terms on the block-scaled 8-bit MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) instead of two more fp16 products; A_lo /
    * W_lo are then not read. out8: the same planes of a half-precision PLAIN output (u8 [2, M, ldc], ldc % 64 == 0),
-   * written next to out / out_lo for the GEMM that consumes it. vdn_pack_weight8 / vdn_layernorm / vdn_flash_attn
-   * produce the planes of weights and of the other activations.                                                    */
+   * written next to out / out_lo for the GEMM that consumes it. vdn_pack_x8 / vdn_layernorm / vdn_flash_attn
+   * (their out8 arguments) produce the planes of weights and of the other activations.                             */
   const void* A8;
   const void* W8;
   void* out8;
+  /* K-tile-major operand planes of the 8-bit cross-term kernel (all 0 = row-major). A 16-bit plane [rows, K] is stored as
+   * [K / 32][rows][32] and a byte plane as [K / 64][rows][64]: the 16 rows x 64 bytes one LDS-DMA instruction moves are then
+   * one contiguous KiB (8 full cache lines) instead of 16 half-used lines — 67 against 44 GB/s per CU of L2 -> LDS feed.
+   *   a_kt:   A and A8 are K-tile-major (lda is ignored; rows = M);   w_kt: W and W8 (rows = N, K extent = ldb; vdn_pack_x8);
+   *   out_kt: a 16-bit PLAIN output (out, out_lo if given, out8) is WRITTEN K-tile-major with rows = M, columns = N == ldc,
+   *           i.e. as the a_kt operand of the next GEMM (bias + GELU / plain half-plane flavours of the 8-bit kernel only).
+   * vdn_layernorm and vdn_flash_attn produce the same layout (their `kt` arguments).                                      */
+  int32_t a_kt, w_kt, out_kt;
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
@@ -176,10 +184,13 @@ int vdn_gemm_set_tuning(const vdn_gemm_tuning* in);
  * memory_attention.py:60,74,93,162 (eps 1e-5), motion_module.py:179,189 (eps 1e-5, with the
  * sinusoidal PE add of :211 fused as addtab), LayerNorm2d sam2_utils.py:148-153 on NHWC rows.
  *   out_group > 0 drops the first row of every `out_group` rows (the cls token, dinov2.py:312)
- *   and writes the remaining rows compacted.                                                     */
+ *   and writes the remaining rows compacted.
+ *   out8 (VDN_F16, C % 64 == 0, optional): u8 [2, rows, C], e5m2(y) and e5m2((y - hi(y)) 2^10): the A8 planes of the GEMM that
+ *   consumes y (out_h_lo may then be NULL). kt != 0: out_h / out_h_lo / out8 are written K-tile-major (vdn_gemm_desc.a_kt). */
 int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
                   const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
-                  int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f, vdn_stream stream);
+                  int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f, void* out8, int kt,
+                  vdn_stream stream);
 
 /* Fused attention forward, head_dim 64: out[b, q, h*64+e] = softmax(scale * Q K^T) V.
  *   Q  half [BH, nq_pad, 64] (rows >= nq never read), K half [BH, nk_pad, 64],
@@ -188,10 +199,13 @@ int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, cons
  * F.scaled_dot_product_attention at sam2/modeling/sam/transformer.py:306.
  *   Q8 / K8 (both or neither; split fp16 planes only): the 8-bit planes vdn_gemm wrote through dst8
  *   (u8 [BH, n_pad, 128]); the two cross terms K_hi Q_lo^T + K_lo Q_hi^T of the scores then run on the block-scaled
- *   8-bit MFMA (e5m2, 2.3x the fp16 rate) instead of two fp16 products; logits stay within ~1e-5. NULL = 3 fp16 products. */
+ *   8-bit MFMA (e5m2, 2.3x the fp16 rate) instead of two fp16 products; logits stay within ~1e-5. NULL = 3 fp16 products.
+ *   out8 (with Q8 / K8 only, optional): u8 [2, B nq, H 64], e5m2(out) and e5m2((out - hi(out)) 2^10): the A8 planes of the
+ *   projection that consumes the output (out_lo may then be NULL); out_kt != 0: out / out_lo / out8 are written K-tile-major
+ *   with rows = B nq (vdn_gemm_desc.a_kt).                                                                                 */
 int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
-                   const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, int B, int H, int nq,
-                   int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
+                   const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, void* out8, int out_kt,
+                   int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
 /* Split-plane mode only: MFMA products per P V term. 2: the softmax weights, born in registers, are
  * rounded once to 16 bits and the row sum uses the same rounded weights (O = sum p~ V / sum p~, V at 21 bits): each
  * weight is off by <= 2^-11 relative, common factors cancel. 3: P is split into hi / lo planes too (every output
@@ -345,6 +359,10 @@ int vdn_pack_rows(int kind, int d0, int d1, int d2);  /* rows of the packed plan
 int vdn_pack_ldb(int kind, int d0, int d1, int d2);   /* plane stride in elements */
 int vdn_pack_weight(int dt, int kind, const float* w, int d0, int d1, int d2, void* hi, void* lo, int ldb, vdn_stream stream);
 int vdn_pack_bias(int kind, const float* b, int d0, int d1, int d2, float* out, vdn_stream stream);
+/* Operand planes of the 8-bit cross-term GEMM (vdn_gemm_desc.W8 / w_kt) from fp16 split planes (hi, lo) [rows, ld] as
+ * vdn_pack_weight wrote them (ld % 64 == 0): planes8 = u8 [2, rows, ld] = e5m2(hi + lo), e5m2(lo 2^10); kt != 0 stores both
+ * K-tile-major ([ld/64][rows][64] each) and, if hi_kt is given, the hi plane again as [ld/32][rows][32].                   */
+int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, vdn_stream stream);
 
 /* Workspace sizing (the library allocates nothing): bytes of split-K scratch worth passing as vdn_gemm_desc.splitk_ws
  * for this descriptor (0 = the shape never splits), and the partial-sum buffer of vdn_groupnorm.

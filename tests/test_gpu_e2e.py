@@ -274,7 +274,7 @@ def test_infer_video_depth_windows_and_stitch():
 
 def test_infer_video_depth_256_frames_vitl_518_full_size():
     """BASELINE configs[3] at FULL size on one GPU (video_depth.py:88-156): a 256-frame ViT-L 518x518 clip = 12 windows,
-    384 window slots over 274 padded frames. Size-independent properties of the driver:
+    384 window slots over 256 distinct frames (the padding repeats the last frame). Size-independent properties of the driver:
       (1) the clip-level tap cache (5.7 GB) and the three-run slot copies: windows 0, 5 and 11 from the cache equal a fresh
           `forward()` of the same 32 window slots (every slot encoded again);
       (2) the 11-push device stitcher chain equals the host restatement `util.stitch` applied to the 12 per-window outputs."""
@@ -291,7 +291,7 @@ def test_infer_video_depth_256_frames_vitl_518_full_size():
     assert d.shape == (n, 518, 518) and fps == 24 and np.isfinite(d).all() and (d >= 0).all()
     d = d.copy()   # the driver's result aliases a reused pinned buffer
     table = util.window_table(n)
-    assert len(table) == 12 and len({f for w in table for f in w}) == 274
+    assert len(table) == 12 and sum(len(w) for w in table) == 384 and len({f for w in table for f in w}) == 256   # 384 window slots, every distinct frame encoded once
     net = model.preprocess_frames(frames, 518)
     per_window = []
     for w, dw in enumerate(model.window_depths(net, table)):

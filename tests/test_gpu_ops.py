@@ -1043,3 +1043,105 @@ def test_nan_in_a_conv_input_reaches_the_output(rt3):
                  conv=dict(B=B, H=H, W=W, C=Ci, OH=H, OW=W, stride=1))
         bad = torch.isnan(out.float()).any(dim=1).reshape(H, W).cpu()
         assert int(bad.sum()) == 9 and bool(bad[5:8, 16:19].all())  # the 3x3 neighbourhood of pixel 137 = (6, 17)
+
+
+# --------------------------------------------------------------------------------------------- 8-bit cross terms, K-tile-major planes
+def _kt16(t, rows, K):   # row-major [rows, K] -> K-tile-major [K/32][rows][32] (include/vdn.h a_kt)
+    return t.reshape(rows, K // 32, 32).permute(1, 0, 2).contiguous()
+
+
+def _kt8(t, rows, K):    # byte plane [rows, K] -> [K/64][rows][64]
+    return t.reshape(rows, K // 64, 64).permute(1, 0, 2).contiguous()
+
+
+def _unkt16(t, rows, K):
+    return t.reshape(K // 32, rows, 32).permute(1, 0, 2).reshape(rows, K)
+
+
+def _unkt8(t, rows, K):
+    return t.reshape(K // 64, rows, 64).permute(1, 0, 2).reshape(rows, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(2740, 1024, 1024), (1370 * 2 + 77, 3072, 384), (2048, 512, 4096), (4100, 1024, 64)])
+def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, tune):
+    """The 8-bit cross-term kernel on K-tile-major operand planes ([K/32][rows][32] halves, [K/64][rows][64] bytes): weights
+    through vdn_pack_x8, activations permuted on the host; bitwise equal to the same kernel on row-major planes (the
+    arithmetic does not depend on the layout), fp64-close; GELU output written K-tile-major with its 8-bit planes and no
+    fp16 lo plane, as fc1 hands it to fc2."""
+    from vdn import pack, _abi
+    from vdn.runtime import HL
+    a = rnd(M, K, seed=990)
+    w = rnd(N, K, seed=991, scale=1 / math.sqrt(K))
+    b, g = rnd(N, seed=992), rnd(N, seed=993)
+    x = rnd(M, N, seed=994)
+    ref = (x.double() + (a.double() @ w.double().t() + b.double()) * g.double()).float()
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    A8, W8 = pack.planes8(A), pack.planes8(W)
+    xr = x.clone().to(DEV)
+    rt3.gemm(A, W, M, N, K, out=xr, bias=b.to(DEV), gamma=g.to(DEV), res1=xr, a8=A8, w8=W8)      # row-major planes
+    X = pack.X8(W)
+    assert torch.equal(_unkt16(X.hi, N, K), W.hi) and torch.equal(_unkt8(X.p8[0], N, K), W8[0]) and torch.equal(_unkt8(X.p8[1], N, K), W8[1])
+    Ak = HL(_kt16(A.hi, M, K))
+    A8k = torch.stack([_kt8(A8[0], M, K), _kt8(A8[1], M, K)]).contiguous()
+    xk = x.clone().to(DEV)
+    rt3.gemm(Ak, HL(X.hi), M, N, K, out=xk, bias=b.to(DEV), gamma=g.to(DEV), res1=xk, a8=A8k, w8=X.p8, a_kt=True, w_kt=True)
+    assert torch.equal(xk, xr)
+    close(xk, ref, 2e-5)
+    if N % 64 == 0:
+        oh = HL(torch.zeros(M, N, dtype=torch.float16, device=DEV))
+        o8 = torch.zeros(2, M, N, dtype=torch.uint8, device=DEV)
+        rt3.gemm(Ak, HL(X.hi), M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8k, w8=X.p8, out8=o8, a_kt=True, w_kt=True, out_kt=True)
+        refg = F.gelu(a.double() @ w.double().t() + b.double()).float()
+        hi = _unkt16(oh.hi, M, N).float()
+        lo = _unkt8(o8[1], M, N).view(torch.float8_e5m2).float() / 1024.0
+        close(hi + lo, refg, 3e-5)                                   # hi + the e5m2 remainder: 2^-14 relative
+        close(_unkt8(o8[0], M, N).view(torch.float8_e5m2).float(), refg, 0.08)   # e5m2(value): 2 mantissa bits
+
+
+@pytest.mark.parametrize("rows,C", [(77, 384), (1370, 1024), (300, 64)])
+def test_layernorm_8bit_planes_and_k_tile_major(rt3, rows, C):
+    """vdn_layernorm(out8, kt): the hi plane + e5m2 (value, remainder 2^10) planes of the 8-bit GEMM's A operand, row-major
+    and K-tile-major, against the plain split-plane output of the same launch."""
+    from vdn.runtime import HL
+    x = rnd(rows, C, seed=995).to(DEV)
+    w, b = rnd(C, seed=996).to(DEV), rnd(C, seed=997).to(DEV)
+    ref = rt3.hbuf(f"t_ln8_ref_{rows}_{C}", (rows, C))
+    rt3.layernorm(x, rows, C, w, b, 1e-6, out_h=ref)
+    for kt in (False, True):
+        oh = HL(torch.zeros(rows, C, dtype=torch.float16, device=DEV))
+        o8 = torch.zeros(2, rows, C, dtype=torch.uint8, device=DEV)
+        rt3.layernorm(x, rows, C, w, b, 1e-6, out_h=oh, out8=o8, kt=kt)
+        hi = _unkt16(oh.hi, rows, C) if kt else oh.hi
+        p0 = _unkt8(o8[0], rows, C) if kt else o8[0]
+        p1 = _unkt8(o8[1], rows, C) if kt else o8[1]
+        assert torch.equal(hi, ref.hi)
+        want0 = ref.float().to(torch.float8_e5m2).view(torch.uint8)
+        want1 = (ref.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)
+        assert (p0.int() - want0.int()).abs().max() <= 1 and (p0 != want0).float().mean() < 2e-3   # ties of the fp32 value vs hi + lo
+        assert torch.equal(p1, want1)
+
+
+def test_flash_attention_8bit_output_planes_k_tile_major(rt3):
+    """vdn_flash_attn(out8, out_kt): the attention output as the proj GEMM's K-tile-major A planes == the row-major planes
+    of the same launch, permuted; remainder plane = e5m2(lo 2^10)."""
+    from vdn import pack, _abi
+    from vdn.runtime import HL
+    B, Hh, T = 2, 3, 150
+    C, tp = Hh * 64, 192
+    qkv = rnd(B * T, 3 * C, seed=998)
+    q, k = rt3.hbuf("t_a8_q", (B * Hh, tp, 64), zero=True), rt3.hbuf("t_a8_k", (B * Hh, tp, 64), zero=True)
+    vt = rt3.hbuf("t_a8_v", (B * Hh, 64, tp), zero=True)
+    q8, k8 = rt3.qk8("t_a8_q8", B * Hh, tp), rt3.qk8("t_a8_k8", B * Hh, tp)
+    w = torch.eye(3 * C)
+    rt3.gemm(rt3.to_half(qkv.to(DEV)), pack.linear(w.to(DEV), rt3.prec), B * T, 3 * C, 3 * C, store=_abi.ST_HEADS,
+             heads=dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=T, tpad=tp))
+    ref = rt3.hbuf("t_a8_ref", (B * T, C))
+    rt3.flash_attn(q, k, vt, ref, B, Hh, T, tp, T, tp, 0.125, q8=q8, k8=k8)
+    oh = HL(torch.zeros(B * T, C, dtype=torch.float16, device=DEV))
+    o8 = torch.zeros(2, B * T, C, dtype=torch.uint8, device=DEV)
+    rt3.flash_attn(q, k, vt, oh, B, Hh, T, tp, T, tp, 0.125, q8=q8, k8=k8, out8=o8, out_kt=True)
+    assert torch.equal(_unkt16(oh.hi, B * T, C), ref.hi)
+    assert torch.equal(_unkt8(o8[1], B * T, C), (ref.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8))
+    want0 = ref.float().to(torch.float8_e5m2).view(torch.uint8)
+    p0 = _unkt8(o8[0], B * T, C)
+    assert (p0.int() - want0.int()).abs().max() <= 1 and (p0 != want0).float().mean() < 2e-3

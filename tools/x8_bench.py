@@ -7,8 +7,9 @@ import torch
 from vdn.runtime import Runtime
 from vdn import pack, _abi
 rt = Runtime(torch.device("cuda:0"), torch.float16, split=True)
+_abi.set_tuning(sk=0)
 torch.manual_seed(0)
-M = 8 * 1370
+M = int(os.environ.get('M', 8 * 1370))
 for name, N, K, kw in (("qkv", 3072, 1024, {}), ("proj", 1024, 1024, {"res": True}), ("fc1", 4096, 1024, {"gelu": True}), ("fc2", 1024, 4096, {"res": True})):
     a = rt.to_half(torch.randn(M, K, device="cuda"))
     w = pack.linear(torch.randn(N, K, device="cuda") / math.sqrt(K), rt.prec)

@@ -689,12 +689,15 @@ int& attn_stream() {
 
 template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
-                 void* outl, const void* Q8, const void* K8, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float sl2, hipStream_t s) {
+                 void* outl, const void* Q8, const void* K8, void* out8, int out_kt, int B, int H, int nq, int nq_pad, int nk, int nk_pad,
+                 float sl2, hipStream_t s) {
   using T = typename Half<DT>::T;
   const dim3 grid(((nq + 127) / 128) * B * H);
   const bool pv3 = pv_products() == 3;  // the 3-product P V with P split into hi / lo planes (vdn_flash_attn_set_pv_products)
   const uint8_t* q8 = (const uint8_t*)Q8;
   const uint8_t* k8 = (const uint8_t*)K8;
+  // the 8-bit / K-tile-major output planes and a lo-less output exist in the default kernel only (fp16 split planes + Q8 / K8)
+  if ((out8 || out_kt || (Ql && !outl)) && !(Ql && !pv3 && q8 && k8 && DT == VDN_F16 && attn_stream() == 2)) return VDN_EUNSUPPORTED;
   if (Ql && pv3)
     hipLaunchKernelGGL((flash_attn_kernel<DT, true, false, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
@@ -707,10 +710,10 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
       const dim3 grid2(((nq + 32 * NW - 1) / (32 * NW)) * B * H);
       if (attn_stream() == 2 && pv_products() == 1)
         hipLaunchKernelGGL((flash_attn2_kernel<1, NW>), grid2, dim3(64 * NW), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
-                           (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+                           (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2, (uint8_t*)out8, out_kt, B * nq);
       else if (attn_stream() == 2)
         hipLaunchKernelGGL((flash_attn2_kernel<2, NW>), grid2, dim3(64 * NW), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
-                           (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
+                           (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2, (uint8_t*)out8, out_kt, B * nq);
       else
       hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                          (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
@@ -760,22 +763,22 @@ extern "C" int vdn_flash_attn_set_stream(int v) {
 extern "C" int vdn_flash_attn_get_stream(void) { return attn_stream(); }
 
 extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
-                              const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, int B, int H,
-                              int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream) {
+                              const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, void* out8,
+                              int out_kt, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream) {
   if (!Q || !K || !Vt || !out || B <= 0 || H <= 0 || nq <= 0 || nk <= 0) return VDN_EINVAL;
   if (nq_pad < nq || nk_pad < nk || (nk_pad & 63)) return VDN_EALIGN;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)out) & 15) return VDN_EALIGN;
   const int nlo = (Q_lo != nullptr) + (K_lo != nullptr) + (Vt_lo != nullptr);
   if (nlo != 0 && nlo != 3) return VDN_EINVAL;  // operand planes are all-or-nothing; the output may be split either way
-  if (nlo == 3 && !out_lo) return VDN_EINVAL;
-  if (((uintptr_t)Q_lo | (uintptr_t)K_lo | (uintptr_t)Vt_lo | (uintptr_t)out_lo | (uintptr_t)Q8 | (uintptr_t)K8) & 15) return VDN_EALIGN;
+  if (nlo == 3 && !out_lo && !out8) return VDN_EINVAL;  // split operands: the output carries its remainder as a 16-bit or an 8-bit plane
+  if (((uintptr_t)Q_lo | (uintptr_t)K_lo | (uintptr_t)Vt_lo | (uintptr_t)out_lo | (uintptr_t)Q8 | (uintptr_t)K8 | (uintptr_t)out8) & 15) return VDN_EALIGN;
   if ((Q8 == nullptr) != (K8 == nullptr) || (Q8 && (nlo != 3 || dt != VDN_F16))) return VDN_EINVAL;  // 8-bit planes come in pairs, split fp16 only
   const float sl2 = scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;
   if (dt == VDN_F16)
-    return flash_launch<VDN_F16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, Q8, K8, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
+    return flash_launch<VDN_F16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, Q8, K8, out8, out_kt, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
   if (dt == VDN_BF16)
-    return flash_launch<VDN_BF16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, nullptr, nullptr, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
+    return flash_launch<VDN_BF16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, nullptr, nullptr, out8, out_kt, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
   return VDN_EUNSUPPORTED;
 }
 

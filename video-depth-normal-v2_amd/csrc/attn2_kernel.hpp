@@ -25,7 +25,8 @@ template <int PV, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_attn2_kernel(
     const _Float16* __restrict__ Q, const _Float16* __restrict__ K, const _Float16* __restrict__ Vt, _Float16* __restrict__ out,
     const _Float16* __restrict__ Kl, const _Float16* __restrict__ Vtl, _Float16* __restrict__ outl, const uint8_t* __restrict__ Q8,
-    const uint8_t* __restrict__ K8, int H, int nq, int nq_pad, int nk, int nk_pad, float scale_log2) {
+    const uint8_t* __restrict__ K8, int H, int nq, int nq_pad, int nk, int nk_pad, float scale_log2, uint8_t* __restrict__ out8,
+    int out_kt, int out_rows) {
   using HT = Half<VDN_F16>;
   using T = _Float16;
   using V8 = typename HT::V8;
@@ -364,21 +365,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int q = q0 + r;
   if (q < nq) {
     const int b = bh / H, hd = bh - b * H;
-    const size_t oo = (((size_t)b * nq + q) * H + hd) * 64;
+    const size_t row = (size_t)b * nq + q;
+    const size_t oo = (row * H + hd) * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         typename HT::V4 v, vl;
+        float f[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           T a, b2;
-          split_rtz(o[db][4 * g + e] * inv, a, b2);
+          f[e] = o[db][4 * g + e] * inv;
+          split_rtz(f[e], a, b2);
           v[e] = a;
           vl[e] = b2;
         }
-        *(typename HT::V4*)(out + oo + db * 32 + 8 * g + 4 * h) = v;
-        *(typename HT::V4*)(outl + oo + db * 32 + 8 * g + 4 * h) = vl;
+        const int c = db * 32 + 8 * g + 4 * h;  // channel inside the head
+        // out_kt: K-tile-major planes for the 8-bit cross-term GEMM that consumes the attention output (vdn_gemm_desc.a_kt):
+        // halves [C/32][rows][32] (the head's two 32-channel tiles are 2 hd + db), bytes [C/64][rows][64] (tile hd)
+        const size_t od = out_kt ? ((size_t)(2 * hd + db) * out_rows + row) * 32 + 8 * g + 4 * h : oo + c;
+        *(typename HT::V4*)(out + od) = v;
+        if (outl) *(typename HT::V4*)(outl + od) = vl;
+        if (out8) {  // e5m2(o) and e5m2(remainder 2^10) (vdn_gemm_desc.A8)
+          uint8_t* d8 = out8 + (out_kt ? ((size_t)hd * out_rows + row) * 64 + c : oo + c);
+          const float k = VDN_LO8_SCALE;
+          *(uint32_t*)d8 = pk4_bf8(f[0], f[1], f[2], f[3]);
+          *(uint32_t*)(d8 + (size_t)out_rows * H * 64) = pk4_bf8(k * (float)vl[0], k * (float)vl[1], k * (float)vl[2], k * (float)vl[3]);
+        }
       }
   }
 #undef A2_IC

@@ -75,8 +75,11 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if (d.out_lo && (d.out_dt == VDN_F32 || !d.out)) return VDN_EINVAL;
   if ((d.res1 && (d.ldr1 & 3)) || (d.res2 && (d.ldr2 & 3))) return VDN_EALIGN;
   if (((uintptr_t)d.A8 | (uintptr_t)d.W8 | (uintptr_t)d.out8) & 15) return VDN_EALIGN;
-  if ((d.A8 || d.W8) && (d.dt != VDN_F16 || d.a_mode != VDN_A_PLAIN || (d.K & 63) || d.lda != d.K)) return VDN_EINVAL;
-  if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || !d.out_lo || (d.ldc & 63))) return VDN_EINVAL;
+  if ((d.A8 || d.W8) && (d.dt != VDN_F16 || d.a_mode != VDN_A_PLAIN || (d.K & 63) || (d.lda != d.K && !d.a_kt))) return VDN_EINVAL;
+  if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || (d.ldc & 63))) return VDN_EINVAL;
+  if ((d.a_kt || d.w_kt || d.out_kt) && (!d.A8 || !d.W8)) return VDN_EINVAL;  // K-tile-major planes: the 8-bit cross-term kernel only
+  if (d.out_kt && (d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || d.ldc != d.N || (d.N & 63) || d.res1 || d.res2 || d.tab ||
+                   d.rowadd || d.gamma || d.row_group > 0 || d.act == VDN_ACT_RELU)) return VDN_EINVAL;
   if (((uintptr_t)d.bias | (uintptr_t)d.gamma | (uintptr_t)d.tab | (uintptr_t)d.res1 | (uintptr_t)d.res2) & 7) return VDN_EALIGN;
   switch (d.store) {
     case VDN_ST_PLAIN:
@@ -102,7 +105,7 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
       for (int i = 0; i < d.nsplit; ++i) {
         if (!d.dst[i] || ((uintptr_t)d.dst[i] & 15)) return VDN_EINVAL;
         if (d.rope[i] && (!d.rope_cs || d.rope_mod <= 0)) return VDN_EINVAL;
-        if (d.dst8[i] && (d.transposed[i] || !d.W_lo || d.dt != VDN_F16 || ((uintptr_t)d.dst8[i] & 15))) return VDN_EINVAL;
+        if (d.dst8[i] && (d.transposed[i] || (!d.W_lo && !d.W8) || d.dt != VDN_F16 || ((uintptr_t)d.dst8[i] & 15))) return VDN_EINVAL;
       }
       break;
     default:

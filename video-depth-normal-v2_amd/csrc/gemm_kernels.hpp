@@ -80,7 +80,7 @@ __host__ __device__ inline int epi_flavour(const vdn_gemm_desc& d) {
     }
   }
   if (d.store == VDN_ST_PLAIN && d.bias && d.act == VDN_ACT_GELU && !d.rowadd && !d.gamma && !d.tab && !d.res1 && !d.res2 &&
-      half_out && d.out_lo && d.row_group <= 0)
+      half_out && (d.out_lo || (d.out8 && d.A8 && d.W8)) && d.row_group <= 0)   // 8-bit kernel: the fp16 lo plane is optional next to out8
     return VDN_STX_FC1;
   if (d.store == VDN_ST_PLAIN && d.act == VDN_ACT_NONE && !d.rowadd && !d.tab && d.res1 && d.res1_dt == VDN_F32 && !d.res1_lo &&
       !d.res2 && d.out_dt == VDN_F32 && d.row_group <= 0)
@@ -107,7 +107,8 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     return;
   } else if constexpr (STORE == VDN_STX_FC1) {  // bias + GELU -> split half planes, plain rows
     a = gelu4(a + bias_a);
-    const size_t o = (size_t)m * p.ldc + n;
+    // out_kt: the planes are written K-tile-major ([N/32][M][32] halves, [N/64][M][64] bytes) for the next 8-bit GEMM
+    const size_t o = p.out_kt ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ldc + n;
     typename H::V4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; e += 2) {
@@ -116,9 +117,9 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
       h[e] = h0; h[e + 1] = h1; l[e] = l0; l[e + 1] = l1;
     }
     *(typename H::V4*)((T*)p.out + o) = h;
-    *(typename H::V4*)((T*)p.out_lo + o) = l;
+    if (p.out_lo) *(typename H::V4*)((T*)p.out_lo + o) = l;
     if (p.out8) {  // 8-bit planes for the consuming GEMM's cross terms: e5m2(v) [M, ldc], then the remainder plane
-      uint8_t* d8 = (uint8_t*)p.out8 + o;
+      uint8_t* d8 = (uint8_t*)p.out8 + (p.out_kt ? ((size_t)(n >> 6) * p.M + m) * 64 + (n & 63) : o);
       const float k = VDN_LO8_SCALE;
       *(uint32_t*)d8 = pk4_bf8(a[0], a[1], a[2], a[3]);
       *(uint32_t*)(d8 + (size_t)p.M * p.ldc) = pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]);
@@ -407,9 +408,19 @@ __device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x
       }
     }
   } else {
-    const size_t o = (size_t)m * p.ldc + n;
+    // out_kt (8-bit cross-term kernel): planes written K-tile-major for the next GEMM ([N/32][M][32] halves, [N/64][M][64] bytes)
+    const size_t o = p.out_kt ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ldc + n;
     *(V8*)((T*)p.out + o) = h;
-    *(V8*)((T*)p.out_lo + o) = l;
+    if (p.out_lo) *(V8*)((T*)p.out_lo + o) = l;
+    if constexpr (STORE == VDN_STX_FC1) {
+      if (p.out8) {  // e5m2(v) and e5m2(remainder 2^10): the A8 planes of the consuming GEMM
+        uint8_t* d8 = (uint8_t*)p.out8 + (p.out_kt ? ((size_t)(n >> 6) * p.M + m) * 64 + (n & 63) : o);
+        const float k = VDN_LO8_SCALE;
+        *(u32x2*)d8 = u32x2{pk4_bf8(a[0], a[1], a[2], a[3]), pk4_bf8(a[4], a[5], a[6], a[7])};
+        *(u32x2*)(d8 + (size_t)p.M * p.ldc) = u32x2{pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]),
+                                                    pk4_bf8(k * (float)l[4], k * (float)l[5], k * (float)l[6], k * (float)l[7])};
+      }
+    }
   }
 }
 
@@ -1637,9 +1648,12 @@ template <int DT>
 int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   // 8-bit cross terms (gemm_x8.hip): plain A, fp16, K a multiple of 64, enough rows to fill 256 x 256 tiles
   if constexpr (DT == VDN_F16) {
-    if (d.A8 && d.W8 && d.a_mode == VDN_A_PLAIN && !d.relu_a && !(d.K & 63) && d.N >= 192 && (long)d.M * d.N >= 1024L * 1024 &&
-        tuning().x8 != 0)
-      return x8_entry(d, s);
+    if (d.A8 && d.W8) {
+      if (d.a_mode == VDN_A_PLAIN && !d.relu_a && !(d.K & 63) && d.N >= 192 && (long)d.M * d.N >= 1024L * 1024 && tuning().x8 != 0)
+        return x8_entry(d, s);
+      // only that kernel reads K-tile-major planes and writes out8 / a lo-less half output
+      if (d.a_kt || d.w_kt || d.out_kt || d.out8 || !d.A_lo || !d.W_lo) return VDN_EUNSUPPORTED;
+    }
   }
   // 8-wave kernels: large problems, and small ones whose deep reduction makes them split-K candidates
   const bool deep = d.splitk_ws && (d.a_mode == VDN_A_CONV3X3 ? d.ldb : d.K) >= 2048 && (long)d.M * d.N >= 32L * 1024;

@@ -4,18 +4,28 @@
 //         + 2^-10 (A8 W_lo8^T + A_lo8 W8^T)  e5m2 v_mfma_scale_f32_32x32x64_f8f6f4   (2 per block and slab, 2.3x the fp16 rate)
 //
 // X8 = e5m2(X), X_lo8 = e5m2((X - X_hi) 2^10) come as two byte planes per operand, shaped like the fp16 operand
-// (u8 [2, rows, K]; include/vdn.h A8 / W8). A cross term is 2^-11 of the product and e5m2 keeps 3 significant bits of it: 2^-14 per term, against 2^-22 for the
-// third fp16 product it replaces and 2^-11 for dropping it. Bytes per element are unchanged (2 + 1 + 1).
+// (u8 [2, rows, K]; include/vdn.h A8 / W8). A cross term is 2^-11 of the product and e5m2 keeps 3 significant bits of it:
+// 2^-14 per term, against 2^-22 for the third fp16 product it replaces and 2^-11 for dropping it. Bytes per
+// element are unchanged (2 + 1 + 1); matrix-pipe cycles per 32 x 32 block and 64 of K drop from 384 to ~240.
 //
 // 256 x 256 tile, 8 waves (2 x 4; a wave owns 128 A rows x 64 W rows = 4 x 2 blocks of 32 x 32, 128 accumulator
 // registers), weights as the MFMA's first operand, so a lane holds one activation row (lane & 31) and runs of 4
 // consecutive output columns: the fp32 epilogues of gemm_kernels.hpp (emit4) apply unchanged.
 //
-// The scaled MFMA needs 64 of K at once, so the unit of the main loop is a 64-deep SLAB = 128 KiB of LDS = all the LDS
-// the kernel has: 8 units of 16 KiB (256 rows x 64 B each: A_hi / W_hi of k 0..31, of k 32..63, and the byte planes
-// W8 + A_lo8, W_lo8 + A8), consumed two at a time by 4 uniform phases and refilled as soon as their phase has been read
-// (see the loop). There is no second buffer at slab granularity — which is also why this kernel does NOT beat the
-// 3-product ping-pong kernel (measurements at the loop): it is an experiment, reachable only through explicit A8 / W8.
+// Structure = the ping-pong of gemm_x3_p8_kernel on 64-deep slabs. A slab is 4 UNITS of 32 KiB (256 rows x 64 B of A and
+// of W each): fp16 k 0..31, fp16 k 32..63, [A_lo8 | W8], [A8 | W_lo8]; unit n = 4 slab + phase is read in global phase n
+// and lives in ring slot n mod NSLOT. The two wave groups (waves 0-3 = A rows 0..127, waves 4-7 = rows 128..255; wave w
+// and w + 4 share a SIMD) run ONE BARRIER APART: between two barriers one group issues 512 matrix-pipe cycles (16 fp16 or
+// 8 scaled MFMAs) on fragments it already holds while the other reads its next 12 fragments and issues its 4 pieces
+// (1 KiB each) of the unit L = NSLOT - 1 phases ahead.
+//   WAR: a wave retires its fragment reads (lgkmcnt(0)) BEFORE the barrier in the middle of its phase, so after the
+//        barrier that ends phase p of the later group every read of unit p has returned and the slot is re-issued in
+//        phase p + 1 by either group (MI355X_MICROARCH.md 'Two waves per SIMD' item 7; guide '256^2 8-phase template').
+//   RAW: a unit issued in phase p is read in phase p + L; before the middle barrier of phase q every wave waits for all
+//        but its 4 (L - 1) newest pieces, i.e. for everything up to unit q + 1; the later group's pieces are covered one
+//        barrier later, still before any read of unit q + 1.
+// NSLOT = 5 uses all 160 KiB of LDS (4 units = 128 KiB in flight or being read); ring slots are addressed by a scalar
+// base, fragment addresses are one VGPR per operand + immediates.
 #include "gemm_kernels.hpp"
 
 namespace vdn_gemm_impl {
@@ -23,19 +33,27 @@ namespace vdn_gemm_impl {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int X8_BM = 256, X8_BN = 256;
-constexpr int X8_U = 256 * 64;  // bytes of one unit: 256 rows x 64 B (32 fp16 or 64 e5m2 per row), 16 KiB
-// LDS map, by phase: [A_hi k0-31 | W_hi k0-31] [A_hi k32-63 | W_hi k32-63] [A_lo8 | W8] [A8 | W_lo8]
-constexpr int X8_LDS = 8 * X8_U;  // 131072
+constexpr int X8_H = 256 * 64;    // bytes of one operand half of a unit: 256 rows x 64 B (32 fp16 or 64 e5m2 per row)
+constexpr int X8_U = 2 * X8_H;    // one unit: A half | W half, 32 KiB
+#ifndef VDN_X8_NSLOT
+#define VDN_X8_NSLOT 5
+#endif
+constexpr int X8_NSLOT = VDN_X8_NSLOT;
+constexpr int X8_LDS = X8_NSLOT * X8_U;
+constexpr int X8_L = X8_NSLOT - 1;  // issue lead in phases
+#ifndef VDN_X8_ABL
+#define VDN_X8_ABL 0   // timing-only builds (tools/build_variant.sh): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads
+#endif
 
 #define X8_GLDS(src, dst)                                                                 \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int STORE>
+// PAIR: the W rows of a tile are loaded in the order that gives every lane 8 consecutive output columns per block row
+template <int STORE, bool PAIR>
 __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   using H = Half<VDN_F16>;
   using V8 = H::V8;
-  using T = H::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -55,44 +73,57 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- DMA geometry: every unit is 16 pieces of 16 rows x 64 B, source chunk (lane & 3) ^ ((-(lane >> 4)) & 3) (the
-  // image of gemm_x3_p8_kernel); wave w moves pieces w and w + 8 of the A unit and of the W unit of a phase: 4 DMA per
-  // thread and phase. Per row the fp16 planes advance 64 B per phase pair, the byte planes 64 B per slab.
+  // ---- DMA geometry: an operand half of a unit is 16 pieces of 16 rows x 64 B, source chunk
+  // (lane & 3) ^ ((-(lane >> 4)) & 3) (the image of gemm_x3_p8_kernel); wave w moves pieces w and w + 8 of the A half and
+  // of the W half: 4 DMA per thread and phase. Per row the fp16 planes advance 64 B per phase, the byte planes 64 B per slab.
   const int lr = lane >> 2, chunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
-  // 32-bit byte offsets of this thread's two pieces inside the fp16 planes (rows clamped; < 2^31: M K <= 2^30 checked on
-  // the host) and inside the byte planes; the slab / phase / plane part of an address is wave-uniform (scalar)
-  unsigned ah_o[2], wh_o[2];  // the byte planes' offsets are (fp16 offset + 16 chunk) / 2: row * K + 16 chunk
+  // Source address of a 16-byte chunk = plane + K-tile index * kts + row * rs + 16 chunk, with (rs, kts) per operand:
+  //   row-major [rows, ld]        fp16: rs = 2 ld, kts = 64 (32 columns)      byte planes: rs = ld, kts = 64 (64 columns)
+  //   K-tile-major (a_kt / w_kt)  fp16 [K/32][rows][32]: rs = 64, kts = 64 rows  bytes [K/64][rows][64]: rs = 64, kts = 64 rows
+  // K-tile-major makes a 16-row piece ONE contiguous KiB (8 full 128-byte lines); a row-major piece touches 16 lines and
+  // uses half of each: measured 44 vs 67 GB/s per CU of L2 -> LDS feed (profiles/r03_x8_ablations.log).
+  const size_t a_rs = p.a_kt ? 64 : (size_t)p.lda * 2, a_kts = p.a_kt ? (size_t)p.M * 64 : 64;
+  const size_t w_rs = p.w_kt ? 64 : (size_t)p.ldb * 2, w_kts = p.w_kt ? (size_t)p.N * 64 : 64;
+  const size_t a8_rs = p.a_kt ? 64 : (size_t)p.lda, a8_kts = p.a_kt ? (size_t)p.M * 64 : 64;
+  const size_t w8_rs = p.w_kt ? 64 : (size_t)p.ldb, w8_kts = p.w_kt ? (size_t)p.N * 64 : 64;
+  // 32-bit byte offsets of this thread's two pieces (rows clamped; < 2^31: rows * ld <= 2^30 checked on the host)
+  unsigned ah_o[2], wh_o[2], a8_o[2], w8_o[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int m = m0 + (wave + 8 * i) * 16 + lr, n = n0 + (wave + 8 * i) * 16 + lr;
+    // plane-output flavours (PAIR): LDS row rho of a W piece holds W row rho with bits 2 and 3 swapped, so that a lane's
+    // accumulator registers 8 u .. 8 u + 7 of a block are 8 CONSECUTIVE output columns (16-byte stores; see the epilogue)
+    const int lrw = PAIR ? ((lr & 3) | ((lr & 4) << 1) | ((lr & 8) >> 1)) : lr;
+    int m = m0 + (wave + 8 * i) * 16 + lr, n = n0 + (wave + 8 * i) * 16 + lrw;
     m = m < p.M ? m : p.M - 1;
     n = n < p.N ? n : p.N - 1;
-    ah_o[i] = ((unsigned)m * (unsigned)p.lda + chunk * 8) * 2;
-    wh_o[i] = ((unsigned)n * (unsigned)p.ldb + chunk * 8) * 2;
+    ah_o[i] = (unsigned)(m * a_rs) + chunk * 16;
+    wh_o[i] = (unsigned)(n * w_rs) + chunk * 16;
+    a8_o[i] = (unsigned)(m * a8_rs) + chunk * 16;
+    w8_o[i] = (unsigned)(n * w8_rs) + chunk * 16;
   }
-  const unsigned c16 = (unsigned)chunk * 16;
-  const char* Ah = (const char*)p.A;               // fp16 [M, K]
-  const char* Wh = (const char*)p.W;               // fp16 [N, ldb]
-  const char* A8v = (const char*)p.A8;             // e5m2(A) [M, K]; the remainder plane follows at + M K bytes
-  const char* W8v = (const char*)p.W8;             // e5m2(W) [N, ldb]; remainder plane at + N ldb bytes
+  const char* Ah = (const char*)p.A;               // fp16 plane
+  const char* Wh = (const char*)p.W;
+  const char* A8v = (const char*)p.A8;             // e5m2(A); the remainder plane follows at + M K bytes
+  const char* W8v = (const char*)p.W8;             // e5m2(W); remainder plane at + N ldb bytes
   const size_t a8l = (size_t)p.M * p.K, w8l = (size_t)p.N * p.ldb;
-  // issue the two units of phase `ph` of slab `slab` into LDS units 2 ph, 2 ph + 1 (ph is a compile-time constant)
-  auto issue = [&](int slab, auto phc) {
+  // issue this wave's 4 pieces of unit (slab, ph) into ring slot `slot` (ph is a compile-time constant)
+  auto issue = [&](int slab, auto phc, int slot) {
     constexpr int ph = decltype(phc)::value;
-    char* ua = smem + (2 * ph) * X8_U;
-    char* uw = ua + X8_U;
+    if constexpr (VDN_X8_ABL & 2) return;
+    char* ua = smem + slot * X8_U;
+    char* uw = ua + X8_H;
     const char *ba, *bw;  // wave-uniform bases
     if constexpr (ph < 2) {
-      ba = Ah + (size_t)slab * 128 + ph * 64;
-      bw = Wh + (size_t)slab * 128 + ph * 64;
+      ba = Ah + (size_t)(2 * slab + ph) * a_kts;
+      bw = Wh + (size_t)(2 * slab + ph) * w_kts;
     } else {  // phase 2: A_lo8 with W8; phase 3: A8 with W_lo8
-      ba = A8v + (ph == 2 ? a8l : 0) + (size_t)slab * 64;
-      bw = W8v + (ph == 2 ? 0 : w8l) + (size_t)slab * 64;
+      ba = A8v + (ph == 2 ? a8l : 0) + (size_t)slab * a8_kts;
+      bw = W8v + (ph == 2 ? 0 : w8l) + (size_t)slab * w8_kts;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      X8_GLDS(ba + (ph < 2 ? ah_o[i] : (ah_o[i] + c16) >> 1), ua + (wave + 8 * i) * 1024);
-      X8_GLDS(bw + (ph < 2 ? wh_o[i] : (wh_o[i] + c16) >> 1), uw + (wave + 8 * i) * 1024);
+      X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
+      X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
     }
   };
 
@@ -100,12 +131,12 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   // fp16 32x32x16 operand, k-step ks (0, 1) of the unit: chunk 2 ks + h. e5m2 32x32x64 operand: bytes 32 h .. 32 h + 31 =
   // chunks 2 h, 2 h + 1.
   // The swizzle term depends on (row >> 2) & 3 = (r >> 2) & 3 only (a wave's blocks start at multiples of 32 rows), so
-  // block i / j of an operand is the block-0 address plus an instruction immediate: 4 address registers in all.
+  // block i / j of an operand is the block-0 address plus an instruction immediate.
   const int swz = (0 - (r >> 2)) & 3;
   const int a_off0 = (wm * 128 + r) * 64 + ((h ^ swz) << 4);
-  const int w_off0 = X8_U + (wn * 64 + r) * 64 + ((h ^ swz) << 4);
+  const int w_off0 = X8_H + (wn * 64 + r) * 64 + ((h ^ swz) << 4);
   const int a8_off0 = (wm * 128 + r) * 64 + (((2 * h) ^ swz) << 4);  // byte operand: chunk 2 h; chunk 2 h + 1 = bit 4 flipped
-  const int w8_off0 = X8_U + (wn * 64 + r) * 64 + (((2 * h) ^ swz) << 4);
+  const int w8_off0 = X8_H + (wn * 64 + r) * 64 + (((2 * h) ^ swz) << 4);
   auto rd8 = [&](const char* u, int off) {
     const u32x4 a0 = *(const u32x4*)(u + off), a1 = *(const u32x4*)(u + (off ^ 16));
     i32x8 v;
@@ -122,12 +153,13 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- phase bodies, split into the fragment READS of a phase and its MFMAs (48 fragment registers either way)
-  V8 hw[2][2], ha[2][4];  // fp16 phases: [k-step][block]
-  i32x8 cw[2], ca[4];     // byte phases
-  auto reads = [&](auto phc) {
+  // ---- phase bodies: the fragment READS of a phase and its MFMAs (48 fragment registers either way)
+  V8 hw[2][2] = {}, ha[2][4] = {};  // fp16 phases: [k-step][block]
+  i32x8 cw[2] = {}, ca[4] = {};     // byte phases
+  auto reads = [&](auto phc, int slot) {
     constexpr int ph = decltype(phc)::value;
-    const char* u = smem + (2 * ph) * X8_U;
+    if constexpr (VDN_X8_ABL & 4) return;
+    const char* u = smem + slot * X8_U;
     if constexpr (ph < 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -143,10 +175,15 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       for (int i = 0; i < 4; ++i) ca[i] = rd8(u + i * 2048, a8_off0);
     }
   };
-  // fp16 phases: A_hi W_hi^T over a 32-deep unit pair (2 k-steps x 8 blocks). Byte phases: one cross term over the slab,
+  // fp16 phases: A_hi W_hi^T over a 32-deep unit (2 k-steps x 8 blocks). Byte phases: one cross term over the slab,
   // phase 2 = W8 A_lo8^T, phase 3 = W_lo8 A8^T (the remainder planes carry 2^10; the E8M0 scale of that operand removes it).
   auto mfmas = [&](auto phc) {
     constexpr int ph = decltype(phc)::value;
+    if constexpr (VDN_X8_ABL & 1) {  // keep the fragments live
+      if constexpr (ph < 2) { for (int ks = 0; ks < 2; ++ks) { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(hw[ks][j])); for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ha[ks][i])); } }
+      else { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(cw[j])); for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ca[i])); }
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
     if constexpr (ph < 2) {
 #pragma unroll
@@ -167,88 +204,206 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- main loop, lock-step: global phase p (= 4 slab + ph) reads unit pair U_{p mod 4}, which is refilled with the data
-  // of phase p + 4 as soon as every wave has read it: three phases of lead and, at any time, three unit pairs (96 KiB) in
-  // flight while one is being read. DMAs complete in issue order and a thread issues 4 per phase, so "all but the three
-  // newest phases" = vmcnt(12); the last slab issues nothing and counts down 12, 8, 4, 0.
-  //
-  // Measured (fc2 shape, M = 10960, N = 1024, K = 4096, tools/x8_bench.py; gemm_x3_p8_kernel = 3.5 us per 64 of K):
-  //   this loop 4.05 us per slab; a ping-pong variant (two wave groups one barrier apart, refill two phases later,
-  //   vmcnt(8) = 64 KiB in flight) 5.3 us, of which DMA-only 3.3 us and MFMA + fragment reads only 2.7 us (ablated builds).
-  //   The feed is LDS-capacity bound: bytes in flight / DMA latency (~1.65 us under load) = 39 GB/s per CU with 64 KiB,
-  //   ~58 GB/s with 96 KiB, i.e. >= 2.2 us per 128-KiB slab — a slab-sized LDS leaves no room to prefetch deeper.
-  //   A 3-bytes-per-element variant was also built and timed (e5m2(X_hi) derived from the fp16 fragments in registers,
-  //   remainder planes stored in the MFMA's slot order, 96 KiB per slab in a 5-slot ring with 128 KiB in flight): 3.86 us
-  //   per slab — with the feed out of the way the loop is bound by its own structure (6 barriers and 36 fragment reads per
-  //   slab around 48 MFMAs per wave), not by bytes. Both lose to gemm_x3_p8_kernel, whose 8-phase ping-pong hides exactly
-  //   that; an 8-bit kernel would need the same treatment on a 3-phase slab. Kept as a tested experiment (the engines do
-  //   not pass A8 / W8).
   const int nslab = p.K >> 6;
+  const int nunits = 4 * nslab;
   constexpr std::integral_constant<int, 0> P0{};
   constexpr std::integral_constant<int, 1> P1{};
   constexpr std::integral_constant<int, 2> P2{};
   constexpr std::integral_constant<int, 3> P3{};
-  issue(0, P0);
-  issue(0, P1);
-  issue(0, P2);
-  issue(0, P3);
-#define X8_PHASE(PC, WAIT, NEXT)                                                                       \
-  do {                                                                                                 \
-    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                           \
-    __builtin_amdgcn_s_barrier(); /* every thread's share of this phase's units has landed */          \
-    reads(PC);                                                                                         \
-    mfmas(PC);                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
-    __builtin_amdgcn_s_barrier(); /* every wave has read them */                                       \
-    NEXT;                                                                                              \
-  } while (0)
-  for (int s = 0; s + 1 < nslab; ++s) {
-    X8_PHASE(P0, 12, issue(s + 1, P0));
-    X8_PHASE(P1, 12, issue(s + 1, P1));
-    X8_PHASE(P2, 12, issue(s + 1, P2));
-    X8_PHASE(P3, 12, issue(s + 1, P3));
+  // ring slots of the unit being read and of the unit being issued (scalars, advanced once per phase)
+  int rd_slot = 0, wr_slot = X8_L % X8_NSLOT;
+  auto next = [](int s) { return s + 1 == X8_NSLOT ? 0 : s + 1; };
+
+  // prologue: the first L units
+  {
+    int s = 0;
+    auto pro = [&](int n, auto phc) {
+      if (n < X8_L && n < nunits) { issue(n >> 2, phc, s); s = next(s); }
+    };
+    pro(0, P0); pro(1, P1); pro(2, P2); pro(3, P3);
+    if constexpr (X8_L > 4) pro(4, P0);
   }
-  X8_PHASE(P0, 12, (void)0);
-  X8_PHASE(P1, 8, (void)0);
-  X8_PHASE(P2, 4, (void)0);
-  X8_PHASE(P3, 0, (void)0);
+  // unit 0 has landed when all but the L - 1 newest units have (short K: fewer units were issued, wait for all)
+  if (nunits >= X8_L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X8_L - 1)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind
+
+  // one phase: [fragment reads of unit n | DMA of unit n + L | counted wait | reads retired] barrier [MFMAs] barrier
+#define X8_PHASE(PC, ISSUE, WAIT)                                      \
+  do {                                                                 \
+    reads(PC, rd_slot);                                                \
+    ISSUE;                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+    __builtin_amdgcn_s_barrier();                                      \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    mfmas(PC);                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    __builtin_amdgcn_s_barrier();                                      \
+    rd_slot = next(rd_slot);                                           \
+    wr_slot = next(wr_slot);                                           \
+  } while (0)
+  // phase ph of slab s issues unit 4 s + ph + L = phase (ph + L) & 3 of slab s + (ph + L) / 4
+#define X8_ISSUE(PH) issue(s + ((PH) + X8_L) / 4, std::integral_constant<int, ((PH) + X8_L) & 3>{}, wr_slot)
+  constexpr int WFULL = 4 * (X8_L - 1);
+  int s = 0;
+  // steady state: every phase of slab s issues (the last unit issued is 4 s + 3 + L <= nunits - 1)
+  for (; 4 * s + 3 + X8_L <= nunits - 1; ++s) {
+    X8_PHASE(P0, X8_ISSUE(0), WFULL);
+    X8_PHASE(P1, X8_ISSUE(1), WFULL);
+    X8_PHASE(P2, X8_ISSUE(2), WFULL);
+    X8_PHASE(P3, X8_ISSUE(3), WFULL);
+  }
+  // tail: the remaining slabs issue only the units that exist; a phase's wait leaves the units beyond n + 1 in flight
+  for (; s < nslab; ++s) {
+    const int n0u = 4 * s;
+#define X8_TAIL(PC, PH)                                                                                   \
+    do {                                                                                                    \
+      const int n = n0u + (PH);                                                                             \
+      const bool doit = n + X8_L <= nunits - 1;                                                             \
+      const int left = nunits - 2 - n + 0; /* units beyond n + 1 that exist */                              \
+      const int inflight = doit ? X8_L - 1 : (left < X8_L - 1 ? (left < 0 ? 0 : left) : X8_L - 1);          \
+      reads(PC, rd_slot);                                                                                   \
+      if (doit) X8_ISSUE(PH);                                                                               \
+      if (inflight >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                  \
+      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
+      else if (inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+      __builtin_amdgcn_s_barrier();                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      mfmas(PC);                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      __builtin_amdgcn_s_barrier();                                                                         \
+      rd_slot = next(rd_slot);                                                                              \
+      wr_slot = next(wr_slot);                                                                              \
+    } while (0)
+    X8_TAIL(P0, 0);
+    X8_TAIL(P1, 1);
+    X8_TAIL(P2, 2);
+    X8_TAIL(P3, 3);
+#undef X8_TAIL
+  }
+#undef X8_ISSUE
 #undef X8_PHASE
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
 
   // ---- epilogue: lane = activation row m (lane & 31); registers 4 g .. 4 g + 3 of block (i, j) = output columns
-  // 32 j + 8 g + 4 h + {0..3}; `b` (GEGLU gate / RoPE partner) is the group 16 columns to the right = registers of g + 2
+  // 32 j + 8 g + 4 h + {0..3} — or, with PAIR, registers 8 u .. 8 u + 7 = columns 32 j + 16 u + 8 h + {0..7}.
+  // Every load (bias, LayerScale, residual) is issued BEFORE the stores it would otherwise queue behind: vmcnt counts loads
+  // and stores in one order, so a load behind a store waits for that store's round trip (measured on the first version of
+  // this epilogue: 42 us per fc1 tile round against 13 us of store bandwidth).
   const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, o4 = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (PAIR) {
+    f32x4 bias8[2][2][2];  // [j][u][half]
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = nw + 32 * j + 8 * g + 4 * h;
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, o4 = {1.f, 1.f, 1.f, 1.f};
-      const f32x4 bias_a = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : z4;
-      const f32x4 bias_b = (p.bias && n + 16 < p.N) ? *(const f32x4*)(p.bias + n + 16) : z4;
-      const f32x4 gam = (p.gamma && n < p.N) ? *(const f32x4*)(p.gamma + n) : o4;
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 a = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        const int gb = (g + 2) & 3;  // only read by flavours that skip the groups where it would wrap
-        const f32x4 b = {acc[i][j][4 * gb], acc[i][j][4 * gb + 1], acc[i][j][4 * gb + 2], acc[i][j][4 * gb + 3]};
-        emit4<VDN_F16, STORE>(p, mw + 32 * i + r, n, a, b, bias_a, bias_b, gam);
+        for (int q = 0; q < 2; ++q) {
+          const int n = nw + 32 * j + 16 * u + 8 * h + 4 * q;
+          bias8[j][u][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : z4;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 a0 = {acc[i][j][8 * u], acc[i][j][8 * u + 1], acc[i][j][8 * u + 2], acc[i][j][8 * u + 3]};
+          const f32x4 a1 = {acc[i][j][8 * u + 4], acc[i][j][8 * u + 5], acc[i][j][8 * u + 6], acc[i][j][8 * u + 7]};
+          emit8<VDN_F16, STORE>(p, mw + 32 * i + r, nw + 32 * j + 16 * u + 8 * h, a0, a1, bias8[j][u][0], bias8[j][u][1]);
+        }
+  } else if constexpr (STORE == VDN_STX_RES) {  // (acc + bias) * gamma + f32 residual -> f32 rows (in place)
+    f32x4 bias4[2][4], gam4[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw + 32 * j + 8 * g + 4 * h;
+        bias4[j][g] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : z4;
+        gam4[j][g] = (p.gamma && n < p.N) ? *(const f32x4*)(p.gamma + n) : o4;
       }
+    f32x4 res[2][2][4];  // the residual of block row i + 1 is fetched before the stores of block row i
+    auto fetch = [&](int i, f32x4 (&dst)[2][4]) {
+      const int m = mw + 32 * i + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nw + 32 * j + 8 * g + 4 * h;
+          dst[j][g] = (m < p.M && n < p.N) ? *(const f32x4*)((const float*)p.res1 + (size_t)m * p.ldr1 + n) : z4;
+        }
+    };
+    fetch(0, res[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i + 1 < 4) fetch(i + 1, res[(i + 1) & 1]);
+      const int m = mw + 32 * i + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nw + 32 * j + 8 * g + 4 * h;
+          const f32x4 a = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (m < p.M && n < p.N) *(f32x4*)((float*)p.out + (size_t)m * p.ldc + n) = (a + bias4[j][g]) * gam4[j][g] + res[i & 1][j][g];
+        }
     }
+  } else {
+    f32x4 bias4[2][4], gam4[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw + 32 * j + 8 * g + 4 * h;
+        bias4[j][g] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : z4;
+        gam4[j][g] = (p.gamma && n < p.N) ? *(const f32x4*)(p.gamma + n) : o4;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw + 32 * j + 8 * g + 4 * h;
+        // `b` (GEGLU gate / RoPE partner) is the group 16 columns to the right = registers of g + 2; only read by flavours
+        // that skip the groups where it would wrap
+        const int gb = (g + 2) & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 a = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          const f32x4 b = {acc[i][j][4 * gb], acc[i][j][4 * gb + 1], acc[i][j][4 * gb + 2], acc[i][j][4 * gb + 3]};
+          emit4<VDN_F16, STORE>(p, mw + 32 * i + r, n, a, b, bias4[j][g], bias4[j][gb], gam4[j][g]);
+        }
+      }
+  }
 }
 #undef X8_GLDS
 
 int x8_entry(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + X8_BM - 1) / X8_BM) * ((d.N + X8_BN - 1) / X8_BN);
   const dim3 g(tiles), b(512);
-#define VDN_X8(ST) hipLaunchKernelGGL((gemm_x8_kernel<ST>), g, b, X8_LDS, s, d)
-  switch (epi_flavour(d)) {
-    case VDN_STX_FC1: VDN_X8(VDN_STX_FC1); break;
-    case VDN_STX_RES: VDN_X8(VDN_STX_RES); break;
-    case VDN_STX_HEADS: VDN_X8(VDN_STX_HEADS); break;
-    case VDN_STX_HALF: VDN_X8(VDN_STX_HALF); break;
-    case VDN_ST_GEGLU: VDN_X8(VDN_ST_GEGLU); break;
-    case VDN_ST_HEADS: VDN_X8(VDN_ST_HEADS); break;
-    default: VDN_X8(VDN_ST_PLAIN); break;
+#define VDN_X8(ST, PAIR)                                                                                               \
+  do {                                                                                                                   \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_x8_kernel<ST, PAIR>,                            \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, X8_LDS); /* once */   \
+    if (attr != hipSuccess) return -(1000 + (int)attr);                                                                  \
+    hipLaunchKernelGGL((gemm_x8_kernel<ST, PAIR>), g, b, X8_LDS, s, d);                                                  \
+  } while (0)
+  int fl = epi_flavour(d);
+  // plane-output flavours store 8 columns (16 bytes) per lane: column counts and strides must keep that aligned
+  const bool a8 = !(d.N & 7) && !(d.ldc & 7) && !((uintptr_t)d.out & 15) && !((uintptr_t)d.out_lo & 15) && !((uintptr_t)d.out8 & 7);
+  if (!a8 && fl != VDN_STX_RES && fl != VDN_STX_HEADS) fl = d.store;
+  if (fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) fl = d.store;
+  switch (fl) {
+    case VDN_STX_FC1: VDN_X8(VDN_STX_FC1, true); break;
+    case VDN_STX_HALF: VDN_X8(VDN_STX_HALF, true); break;
+    case VDN_STX_HEADS: VDN_X8(VDN_STX_HEADS, true); break;
+    case VDN_STX_RES: VDN_X8(VDN_STX_RES, false); break;
+    case VDN_ST_GEGLU: VDN_X8(VDN_ST_GEGLU, false); break;
+    case VDN_ST_HEADS: VDN_X8(VDN_ST_HEADS, false); break;
+    default: VDN_X8(VDN_ST_PLAIN, false); break;
   }
 #undef VDN_X8
   VDN_CHECK_LAUNCH();

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
                                                         const float* __restrict__ addtab, int tab_div, int tab_mod,
                                                         int out_group, typename Half<DT>::T* __restrict__ out_h,
                                                         typename Half<DT>::T* __restrict__ out_l,
-                                                        float* __restrict__ out_f) {
+                                                        float* __restrict__ out_f, uint8_t* __restrict__ out8, int kt) {
   using T = typename Half<DT>::T;
   using XV = typename Vec4<XT>::V;
   const int lane = threadIdx.x & 63;
@@ -82,19 +82,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
           if (out_f) *(f32x4*)(out_f + orow * C + c) = y;
           if (out_h) {
             typename Half<DT>::V4 hv, lv;
-            if (out_l) {
+            // kt: K-tile-major planes for the 8-bit cross-term GEMM (include/vdn.h a_kt): [C/32][rows][32] halves, [C/64][rows][64] bytes
+            const size_t oh = kt ? ((size_t)(c >> 5) * rows + orow) * 32 + (c & 31) : orow * C + c;
+            if (out_l || out8) {
 #pragma unroll
               for (int e = 0; e < 4; e += 2) {
                 T h0, h1, l0, l1;
                 split2_rtz(y[e], y[e + 1], h0, h1, l0, l1);
                 hv[e] = h0; hv[e + 1] = h1; lv[e] = l0; lv[e + 1] = l1;
               }
-              *(typename Half<DT>::V4*)(out_l + orow * C + c) = lv;
+              if (out_l) *(typename Half<DT>::V4*)(out_l + oh) = lv;
+              if (out8) {  // e5m2(y) and e5m2(remainder 2^10) (vdn_gemm_desc.A8)
+                uint8_t* d8 = out8 + (kt ? ((size_t)(c >> 6) * rows + orow) * 64 + (c & 63) : orow * C + c);
+                const float k = VDN_LO8_SCALE;
+                *(uint32_t*)d8 = pk4_bf8(y[0], y[1], y[2], y[3]);
+                *(uint32_t*)(d8 + (size_t)rows * C) = pk4_bf8(k * (float)lv[0], k * (float)lv[1], k * (float)lv[2], k * (float)lv[3]);
+              }
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) hv[e] = (T)y[e];
             }
-            *(typename Half<DT>::V4*)(out_h + orow * C + c) = hv;
+            *(typename Half<DT>::V4*)(out_h + oh) = hv;
           }
         }
       }
@@ -250,7 +258,7 @@ __global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restric
 template <typename XT, int NV>
 int ln_launch_nv(const void* x, int rows, int C, const float* w, const float* b, float eps, const float* addvec,
                  float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, void* out_l,
-                 int h_dt, float* out_f, hipStream_t s) {
+                 int h_dt, float* out_f, void* out8, int kt, hipStream_t s) {
   // grid = what is resident at once (CUs x blocks the register budget admits), persistent beyond that
   static const int resident = [] {
     int per_cu = 0, dev = 0;
@@ -264,10 +272,10 @@ int ln_launch_nv(const void* x, int rows, int C, const float* w, const float* b,
   const dim3 grid(blocks < resident ? blocks : resident);
   if (h_dt == VDN_BF16)
     hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16, NV>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
-                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, (__bf16*)out_l, out_f);
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, (__bf16*)out_l, out_f, (uint8_t*)nullptr, 0);
   else
     hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16, NV>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
-                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f);
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f, (uint8_t*)out8, kt);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
@@ -275,30 +283,31 @@ int ln_launch_nv(const void* x, int rows, int C, const float* w, const float* b,
 template <typename XT>
 int ln_launch(const void* x, int rows, int C, const float* w, const float* b, float eps, const float* addvec,
               float alpha, const float* addtab, int tab_div, int tab_mod, int out_group, void* out_h, void* out_l,
-              int h_dt, float* out_f, hipStream_t s) {
+              int h_dt, float* out_f, void* out8, int kt, hipStream_t s) {
   if (C <= 512)
-    return ln_launch_nv<XT, 2>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, s);
+    return ln_launch_nv<XT, 2>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, out8, kt, s);
   if (C <= 1024)
-    return ln_launch_nv<XT, 4>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, s);
-  return ln_launch_nv<XT, 8>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, s);
+    return ln_launch_nv<XT, 4>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, out8, kt, s);
+  return ln_launch_nv<XT, 8>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_l, h_dt, out_f, out8, kt, s);
 }
 
 }  // namespace
 
 extern "C" int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
                              const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
-                             int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f,
+                             int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f, void* out8, int kt,
                              vdn_stream stream) {
   if (!x || !w || !b || rows <= 0 || C <= 0 || (!out_h && !out_f)) return VDN_EINVAL;
   if ((C & 3) || C > 2048) return VDN_EALIGN;
   if (addtab && (tab_div <= 0 || tab_mod <= 0)) return VDN_EINVAL;
   if (out_h && h_dt != VDN_F16 && h_dt != VDN_BF16) return VDN_EUNSUPPORTED;
+  if ((out8 || kt) && (!out_h || h_dt != VDN_F16 || out_group > 0 || (C & 63) || ((uintptr_t)out8 & 15))) return VDN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (!addtab) { tab_div = 1; tab_mod = 1; }
   switch (x_dt) {
-    case VDN_F32: return ln_launch<float>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, s);
-    case VDN_F16: return ln_launch<_Float16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, s);
-    case VDN_BF16: return ln_launch<__bf16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, s);
+    case VDN_F32: return ln_launch<float>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, out8, kt, s);
+    case VDN_F16: return ln_launch<_Float16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, out8, kt, s);
+    case VDN_BF16: return ln_launch<__bf16>(x, rows, C, w, b, eps, addvec, alpha, addtab, tab_div, tab_mod, out_group, out_h, out_h_lo, h_dt, out_f, out8, kt, s);
     default: return VDN_EUNSUPPORTED;
   }
 }

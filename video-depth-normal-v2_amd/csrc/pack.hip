@@ -131,6 +131,38 @@ extern "C" int vdn_pack_bias(int kind, const float* b, int d0, int d1, int d2, f
   return VDN_OK;
 }
 
+namespace {
+// Operand planes of the 8-bit cross-term GEMM from packed fp16 split planes (include/vdn.h: vdn_pack_x8): the hi plane again
+// K-tile-major and the two e5m2 planes (value, remainder 2^10), K-tile-major or row-major. One thread per 4 elements.
+__global__ __launch_bounds__(256) void pack_x8_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int rows,
+                                                      int ld, _Float16* __restrict__ hi_kt, uint8_t* __restrict__ p8, int kt) {
+  const size_t total = (size_t)rows * (ld >> 2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / (ld >> 2)), k = (int)(i - (size_t)r * (ld >> 2)) * 4;
+    const f16x4 h = *(const f16x4*)(hi + (size_t)r * ld + k);
+    const f16x4 l = *(const f16x4*)(lo + (size_t)r * ld + k);
+    if (hi_kt) *(f16x4*)(hi_kt + ((size_t)(k >> 5) * rows + r) * 32 + (k & 31)) = h;
+    const size_t o8 = kt ? ((size_t)(k >> 6) * rows + r) * 64 + (k & 63) : (size_t)r * ld + k;
+    const float s = VDN_LO8_SCALE;
+    *(uint32_t*)(p8 + o8) = pk4_bf8((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+    *(uint32_t*)(p8 + (size_t)rows * ld + o8) = pk4_bf8(s * (float)l[0], s * (float)l[1], s * (float)l[2], s * (float)l[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, vdn_stream stream) {
+  if (!hi || !lo || !planes8 || rows <= 0 || ld <= 0 || (ld & 63)) return VDN_EINVAL;
+  if (((uintptr_t)hi | (uintptr_t)lo | (uintptr_t)hi_kt | (uintptr_t)planes8) & 15) return VDN_EALIGN;
+  if (hi_kt && !kt) return VDN_EINVAL;
+  const size_t work = (size_t)rows * (ld >> 2);
+  const dim3 g((unsigned)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192));
+  hipLaunchKernelGGL(pack_x8_kernel, g, dim3(256), 0, (hipStream_t)stream, (const _Float16*)hi, (const _Float16*)lo, rows, ld,
+                     (_Float16*)hi_kt, (uint8_t*)planes8, kt);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
 // Scratch a caller should hand to vdn_gemm (splitk_ws) so that this launch may split K: 0 when the shape never does.
 extern "C" size_t vdn_gemm_workspace_bytes(const vdn_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || !d->A_lo || !d->W_lo) return 0;

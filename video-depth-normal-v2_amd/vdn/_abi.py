@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("ksplit", i32),
         ("dst8", vp * 3),
         ("A8", vp), ("W8", vp), ("out8", vp),
+        ("a_kt", i32), ("w_kt", i32), ("out_kt", i32),
     ]
 
 
@@ -70,9 +71,9 @@ EXPORTS = {
     "vdn_gemm_get_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
     "vdn_gemm_set_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
     "vdn_layernorm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_float, fp, C.c_int, C.c_int,
-                                C.c_int, vp, vp, C.c_int, fp, vp]),
-    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_int, C.c_float, vp]),
+                                C.c_int, vp, vp, C.c_int, fp, vp, C.c_int, vp]),
+    "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_float, vp]),
     "vdn_flash_attn_set_pv_products": (C.c_int, [C.c_int]),
     "vdn_flash_attn_get_pv_products": (C.c_int, []),
     "vdn_flash_attn_set_stream": (C.c_int, [C.c_int]),
@@ -93,6 +94,7 @@ EXPORTS = {
     "vdn_pack_ldb": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "vdn_pack_weight": (C.c_int, [C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "vdn_pack_bias": (C.c_int, [C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, vp]),
+    "vdn_pack_x8": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "vdn_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "vdn_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vdn_mask_down1": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),

@@ -58,6 +58,13 @@ class EncoderEngine:
             self.blocks.append(blk)
         self.nw, self.nb = pack.f32(mod.norm.weight), pack.f32(mod.norm.bias)
         self._pos_cache = {}
+        # 8-bit cross terms for the four linears of a block (csrc/gemm_x8.hip): fp16 split planes only, K-tile-major
+        # weight planes made once here. VDN_X8=0 keeps the three-fp16-product kernels.
+        self.x8 = (rt.split and rt.half == torch.float16 and not cfg.get("swiglu") and self.C % 64 == 0
+                   and os.environ.get("VDN_X8", "1") != "0")
+        if self.x8:
+            for blk in self.blocks:
+                blk["x8"] = {k: pack.X8(blk[k]) for k in ("wqkv", "wproj", "wfc1", "wfc2")}
 
     def _pos_for(self, ph: int, pw: int):
         """interpolate_pos_encoding (dinov2.py:179-210): identity for the square 37x37 grid, else bicubic
@@ -98,27 +105,51 @@ class EncoderEngine:
         k = rt.hbuf("enc_k", (Bf * Hh, npad, 64), zero=True)
         vt = rt.hbuf("enc_vt", (Bf * Hh, 64, npad), zero=True)
         q8, k8 = rt.qk8("enc_q8", Bf * Hh, npad), rt.qk8("enc_k8", Bf * Hh, npad)  # e5m2 planes for the score cross terms
-        hn = rt.hbuf("enc_ln", (M, C))
-        att = rt.hbuf("enc_att", (M, C))
         Hd = self.hidden
-        f1 = rt.hbuf("enc_fc1", (M, Hd))
         heads = dict(dst=[rt.qk_dst(q, q8), rt.qk_dst(k, k8), rt.v_dst(vt)], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=N, tpad=npad)
         outs, last_f32 = [], None
         readout = getattr(self, "readout", None)   # ReadoutEngine when the head was built with use_clstoken
         probe = getattr(self, "probe", None)   # tests only: callable(block index, fp32 token stream [M, C]); -1 = input of block 0
         if probe is not None:
             probe(-1, tok)
+        # 8-bit cross-term path: large batches only (its kernel has 256 x 256 tiles: M >= 4096 keeps every launch near a
+        # round of the chip or more), with the default attention (the only producer of the 8-bit output planes)
+        use8 = (self.x8 and M >= 4096 and q8 is not None and abi.lib.vdn_flash_attn_get_pv_products() != 3
+                and abi.lib.vdn_flash_attn_get_stream() == 2)
+        if use8:
+            from .runtime import HL
+            # activations between the linears as K-tile-major planes: fp16 hi + e5m2 (value, remainder) — no fp16 lo plane
+            hn_k, hn8 = HL(rt.buf("enc_ln_kt", (M, C), rt.half)), rt.buf("enc_ln8", (2, M, C), torch.uint8)
+            att_k, att8 = HL(rt.buf("enc_att_kt", (M, C), rt.half)), rt.buf("enc_att8", (2, M, C), torch.uint8)
+            f1_k, f18 = HL(rt.buf("enc_fc1_kt", (M, Hd), rt.half)), rt.buf("enc_fc18", (2, M, Hd), torch.uint8)
+            kt = dict(a_kt=True, w_kt=True)
+        else:
+            hn, att, f1 = rt.hbuf("enc_ln", (M, C)), rt.hbuf("enc_att", (M, C)), rt.hbuf("enc_fc1", (M, Hd))
         for i, b in enumerate(self.blocks):
-            rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
-            rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear")
-            rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn", q8=q8, k8=k8)
-            rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear")
-            rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
-            if self.cfg.get("swiglu"):
-                rt.gemm(hn, b["wfc1"], M, 2 * Hd, C, bias=b["bfc1"], store=abi.ST_GEGLU, act=abi.ACT_SILU, out=f1, tag="enc_linear")
+            if use8:
+                x8 = b["x8"]
+                rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn_k, out8=hn8, kt=True)
+                rt.gemm(hn_k, HL(x8["wqkv"].hi), M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear",
+                        a8=hn8, w8=x8["wqkv"].p8, **kt)
+                rt.flash_attn(q, k, vt, att_k, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn", q8=q8, k8=k8, out8=att8, out_kt=True)
+                rt.gemm(att_k, HL(x8["wproj"].hi), M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear",
+                        a8=att8, w8=x8["wproj"].p8, **kt)
+                rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn_k, out8=hn8, kt=True)
+                rt.gemm(hn_k, HL(x8["wfc1"].hi), M, Hd, C, bias=b["bfc1"], act=GELU, out=f1_k, out8=f18, out_kt=True, tag="enc_linear",
+                        a8=hn8, w8=x8["wfc1"].p8, **kt)
+                rt.gemm(f1_k, HL(x8["wfc2"].hi), M, C, Hd, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear",
+                        a8=f18, w8=x8["wfc2"].p8, **kt)
             else:
-                rt.gemm(hn, b["wfc1"], M, Hd, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
-            rt.gemm(f1, b["wfc2"], M, C, Hd, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
+                rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
+                rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear")
+                rt.flash_attn(q, k, vt, att, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn", q8=q8, k8=k8)
+                rt.gemm(att, b["wproj"], M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear")
+                rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn)
+                if self.cfg.get("swiglu"):
+                    rt.gemm(hn, b["wfc1"], M, 2 * Hd, C, bias=b["bfc1"], store=abi.ST_GEGLU, act=abi.ACT_SILU, out=f1, tag="enc_linear")
+                else:
+                    rt.gemm(hn, b["wfc1"], M, Hd, C, bias=b["bfc1"], act=GELU, out=f1, tag="enc_linear")
+                rt.gemm(f1, b["wfc2"], M, C, Hd, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear")
             if probe is not None:
                 probe(i, tok)
             if i in self.taps:

@@ -148,6 +148,21 @@ def planes8(t) -> torch.Tensor:
     return torch.stack([v8, l8]).contiguous()
 
 
+class X8:
+    """Weight planes of the 8-bit cross-term GEMM (include/vdn.h W8 / w_kt): the fp16 hi plane K-tile-major
+    ([ld/32][N][32]) and the two e5m2 planes u8 [2][ld/64][N][64], made on the device by vdn_pack_x8."""
+    __slots__ = ("hi", "p8", "rows", "ld")
+
+    def __init__(self, w):
+        from . import _abi as abi
+        assert w.lo is not None and w.hi.dtype == torch.float16 and w.hi.shape[1] % 64 == 0
+        self.rows, self.ld = w.hi.shape
+        self.hi = torch.empty_like(w.hi)
+        self.p8 = torch.empty((2, self.rows, self.ld), dtype=torch.uint8, device=w.hi.device)
+        abi.check(abi.lib.vdn_pack_x8(w.hi.data_ptr(), w.lo.data_ptr(), self.rows, self.ld, self.hi.data_ptr(),
+                                      self.p8.data_ptr(), 1, _stream(w.hi)), "vdn_pack_x8")
+
+
 def rope_table(side_y: int, side_x: int, dim: int = 64, theta: float = 10000.0, device=None) -> torch.Tensor:
     """(cos, sin) of sam2 compute_axial_cis (position_encoding.py:192-201): f32 [side_y*side_x, dim/2, 2].
     Pairs 0..dim/4-1 rotate with the x coordinate, dim/4..dim/2-1 with y."""

@@ -155,7 +155,8 @@ class Runtime:
              rowadd=None, tab=None, tab_mod: int = 0, tab_off: int = 0, res1=None, ldr1=None, res2=None, ldr2=None,
              conv: Optional[dict] = None, relu_a: bool = False, store: int = abi.ST_PLAIN, row_group: int = 0,
              row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None, tag: Optional[str] = None,
-             a8: Optional[torch.Tensor] = None, w8: Optional[torch.Tensor] = None, out8: Optional[torch.Tensor] = None):
+             a8: Optional[torch.Tensor] = None, w8: Optional[torch.Tensor] = None, out8: Optional[torch.Tensor] = None,
+             a_kt: bool = False, w_kt: bool = False, out_kt: bool = False):
         d = abi.GemmDesc()
         d.dt = self.dt
         d.M, d.N, d.K = M, N, K
@@ -217,6 +218,7 @@ class Runtime:
             d.A8, d.W8 = a8.data_ptr(), w8.data_ptr()
         if out8 is not None:
             d.out8 = out8.data_ptr()
+        d.a_kt, d.w_kt, d.out_kt = int(a_kt), int(w_kt), int(out_kt)   # K-tile-major planes (include/vdn.h)
         d.cu_hint = self.cu_hint
         if self.split:  # split-K scratch for launches whose tile grid covers a fraction of the chip (include/vdn.h)
             ws = self.buf("splitk_ws", (32 * 1024 * 1024,), torch.float32)
@@ -225,18 +227,22 @@ class Runtime:
         return out
 
     def layernorm(self, x: torch.Tensor, rows: int, Cn: int, w, b, eps: float, *, out_h=None, out_f=None, addvec=None,
-                  alpha: float = 1.0, addtab=None, tab_div: int = 1, tab_mod: int = 1, out_group: int = 0):
+                  alpha: float = 1.0, addtab=None, tab_div: int = 1, tab_mod: int = 1, out_group: int = 0, out8=None,
+                  kt: bool = False):
+        """out8: u8 [2, rows, C] e5m2 planes of the output for the 8-bit cross-term GEMM; kt: K-tile-major planes."""
         oh, ol = _hl(out_h) if out_h is not None else (None, None)
         self._launch(abi.lib.vdn_layernorm, x.data_ptr(), _TDT[x.dtype], rows, Cn, w.data_ptr(), b.data_ptr(), eps,
                      self._p(addvec), alpha, self._p(addtab), tab_div, tab_mod, out_group, self._p(oh), ol, self.dt,
-                     self._p(out_f))
+                     self._p(out_f), self._p(out8), int(kt))
 
     def flash_attn(self, Q, K, Vt, out, B: int, H: int, nq: int, nq_pad: int, nk: int, nk_pad: int, scale: float,
-                   tag: Optional[str] = None, q8: Optional[torch.Tensor] = None, k8: Optional[torch.Tensor] = None):
-        """q8 / k8: the u8 [B*H, n_pad, 128] planes the projection wrote through heads['dst8'] (8-bit cross terms)."""
+                   tag: Optional[str] = None, q8: Optional[torch.Tensor] = None, k8: Optional[torch.Tensor] = None,
+                   out8: Optional[torch.Tensor] = None, out_kt: bool = False):
+        """q8 / k8: the u8 [B*H, n_pad, 128] planes the projection wrote through heads['dst8'] (8-bit cross terms).
+        out8 / out_kt: e5m2 planes of the output and the K-tile-major layout for the 8-bit cross-term GEMM that follows."""
         (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
         self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
-                     vl, ol, self._p(q8), self._p(k8), B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag,
+                     vl, ol, self._p(q8), self._p(k8), self._p(out8), int(out_kt), B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag,
                      flop=4.0 * B * H * nq * nk * 64)
 
     def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
