@@ -147,7 +147,11 @@ def _lanes_against_single_lane_and_fixture(name, enc, B, monkeypatch):
     for t in range(steps):
         e = rel_l2(runs["2"][t], runs["1"][t])
         worst_l = max(worst_l, e)
-        assert e < 3e-6, (t, e)  # same arithmetic; only the split-K slicing follows the lane's CU share
+        # same arithmetic; only the split-K slicing follows the lane's CU share — unless the lane's half batch falls under the
+        # row count from which the encoder linears run on the 8-bit cross-term kernel (engine.py: M >= 4096) while the whole
+        # batch does not: two fp32-faithful kernels then differ by their cross-term rounding (2^-14 per term)
+        N = (H // 14) * (W // 14) + 1
+        assert e < (3e-6 if (B // 2 * N >= 4096) == (B * N >= 4096) else 3e-4), (t, e)
         if t in kept:
             for lanes in ("2", "1"):
                 ef = rel_l2(torch.relu(runs[lanes][t][0, ::sub, ::sub]), np.maximum(g[f"pre_{t}"][0], 0))

@@ -1062,14 +1062,16 @@ def _unkt8(t, rows, K):
     return t.reshape(K // 64, rows, 64).permute(1, 0, 2).reshape(rows, K)
 
 
+@pytest.mark.parametrize("bm", [0, 192, 256])
 @pytest.mark.parametrize("M,N,K", [(2740, 1024, 1024), (1370 * 2 + 77, 3072, 384), (2048, 512, 4096), (4100, 1024, 64)])
-def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, tune):
+def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
     """The 8-bit cross-term kernel on K-tile-major operand planes ([K/32][rows][32] halves, [K/64][rows][64] bytes): weights
     through vdn_pack_x8, activations permuted on the host; bitwise equal to the same kernel on row-major planes (the
     arithmetic does not depend on the layout), fp64-close; GELU output written K-tile-major with its 8-bit planes and no
     fp16 lo plane, as fc1 hands it to fc2."""
     from vdn import pack, _abi
     from vdn.runtime import HL
+    tune(force_bm=bm)   # 0: the launch picks its M tile (192 or 256 rows); else pinned — the results must not depend on it
     a = rnd(M, K, seed=990)
     w = rnd(N, K, seed=991, scale=1 / math.sqrt(K))
     b, g = rnd(N, seed=992), rnd(N, seed=993)

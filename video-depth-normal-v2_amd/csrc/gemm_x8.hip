@@ -32,14 +32,15 @@ namespace vdn_gemm_impl {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int X8_BM = 256, X8_BN = 256;
-constexpr int X8_H = 256 * 64;    // bytes of one operand half of a unit: 256 rows x 64 B (32 fp16 or 64 e5m2 per row)
-constexpr int X8_U = 2 * X8_H;    // one unit: A half | W half, 32 KiB
+constexpr int X8_BN = 256;
+constexpr int X8_WH = 256 * 64;   // bytes of the W half of a unit: 256 rows x 64 B (32 fp16 or 64 e5m2 per row)
+// BM = 256 | 192 rows of A per tile (chosen per launch so that the tile count fills whole rounds of the CUs, x8_entry):
+// the A half of a unit is BM rows x 64 B, a wave owns BM / 2 rows = NI blocks of 32.
 #ifndef VDN_X8_NSLOT
 #define VDN_X8_NSLOT 5
 #endif
 constexpr int X8_NSLOT = VDN_X8_NSLOT;
-constexpr int X8_LDS = X8_NSLOT * X8_U;
+constexpr int x8_unit(int bm) { return bm * 64 + X8_WH; }  // 32 KiB (BM 256) or 28 KiB (BM 192)
 constexpr int X8_L = X8_NSLOT - 1;  // issue lead in phases
 #ifndef VDN_X8_ABL
 #define VDN_X8_ABL 0   // timing-only builds (tools/build_variant.sh): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads
@@ -50,10 +51,12 @@ constexpr int X8_L = X8_NSLOT - 1;  // issue lead in phases
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 // PAIR: the W rows of a tile are loaded in the order that gives every lane 8 consecutive output columns per block row
-template <int STORE, bool PAIR>
+template <int STORE, bool PAIR, int X8_BM>
 __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   using H = Half<VDN_F16>;
   using V8 = H::V8;
+  static_assert(X8_BM == 256 || X8_BM == 192, "two wave groups of 4 or 3 blocks of 32 rows");
+  constexpr int X8_H = X8_BM * 64, X8_U = x8_unit(X8_BM), NI = X8_BM / 64, AP = X8_BM / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -122,10 +125,18 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
+      if (AP == 16 || wave + 8 * i < AP) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
       X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
     }
   };
+  // pieces this wave issues per unit: 4, or 3 for waves 4-7 of the 192-row tile (12 A pieces over 8 waves); the counted
+  // waits below are in UNITS left in flight
+  const bool four = AP == 16 || wave < 4;
+#define X8_WAIT_UNITS(K)                                                          \
+  do {                                                                            \
+    if (four) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K)) : "memory");      \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (K)) : "memory");           \
+  } while (0)
 
   // ---- fragment addresses inside a unit (64-byte rows): 16-byte chunk c of row `row` sits at c ^ ((-(row >> 2)) & 3).
   // fp16 32x32x16 operand, k-step ks (0, 1) of the unit: chunk 2 ks + h. e5m2 32x32x64 operand: bytes 32 h .. 32 h + 31 =
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   // The swizzle term depends on (row >> 2) & 3 = (r >> 2) & 3 only (a wave's blocks start at multiples of 32 rows), so
   // block i / j of an operand is the block-0 address plus an instruction immediate.
   const int swz = (0 - (r >> 2)) & 3;
-  const int a_off0 = (wm * 128 + r) * 64 + ((h ^ swz) << 4);
+  const int a_off0 = (wm * (X8_BM / 2) + r) * 64 + ((h ^ swz) << 4);
   const int w_off0 = X8_H + (wn * 64 + r) * 64 + ((h ^ swz) << 4);
-  const int a8_off0 = (wm * 128 + r) * 64 + (((2 * h) ^ swz) << 4);  // byte operand: chunk 2 h; chunk 2 h + 1 = bit 4 flipped
+  const int a8_off0 = (wm * (X8_BM / 2) + r) * 64 + (((2 * h) ^ swz) << 4);  // byte operand: chunk 2 h; chunk 2 h + 1 = bit 4 flipped
   const int w8_off0 = X8_H + (wn * 64 + r) * 64 + (((2 * h) ^ swz) << 4);
   auto rd8 = [&](const char* u, int off) {
     const u32x4 a0 = *(const u32x4*)(u + off), a1 = *(const u32x4*)(u + (off ^ 16));
@@ -145,17 +156,17 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     return v;
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- phase bodies: the fragment READS of a phase and its MFMAs (48 fragment registers either way)
-  V8 hw[2][2] = {}, ha[2][4] = {};  // fp16 phases: [k-step][block]
-  i32x8 cw[2] = {}, ca[4] = {};     // byte phases
+  V8 hw[2][2] = {}, ha[2][NI] = {};  // fp16 phases: [k-step][block]
+  i32x8 cw[2] = {}, ca[NI] = {};     // byte phases
   auto reads = [&](auto phc, int slot) {
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 4) return;
@@ -166,13 +177,13 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) hw[ks][j] = *(const V8*)(u + (w_off0 ^ (ks << 5)) + j * 2048);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ha[ks][i] = *(const V8*)(u + (a_off0 ^ (ks << 5)) + i * 2048);
+        for (int i = 0; i < NI; ++i) ha[ks][i] = *(const V8*)(u + (a_off0 ^ (ks << 5)) + i * 2048);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) cw[j] = rd8(u + j * 2048, w8_off0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ca[i] = rd8(u + i * 2048, a8_off0);
+      for (int i = 0; i < NI; ++i) ca[i] = rd8(u + i * 2048, a8_off0);
     }
   };
   // fp16 phases: A_hi W_hi^T over a 32-deep unit (2 k-steps x 8 blocks). Byte phases: one cross term over the slab,
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   auto mfmas = [&](auto phc) {
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 1) {  // keep the fragments live
-      if constexpr (ph < 2) { for (int ks = 0; ks < 2; ++ks) { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(hw[ks][j])); for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ha[ks][i])); } }
-      else { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(cw[j])); for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ca[i])); }
+      if constexpr (ph < 2) { for (int ks = 0; ks < 2; ++ks) { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(hw[ks][j])); for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(ha[ks][i])); } }
+      else { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(cw[j])); for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(ca[i])); }
       return;
     }
     __builtin_amdgcn_s_setprio(1);
@@ -189,12 +200,12 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = H::mfma32(hw[ks][j], ha[ks][i], acc[i][j]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, 127, 0, VDN_LO8_E8M0);
@@ -206,6 +217,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 
   const int nslab = p.K >> 6;
   const int nunits = 4 * nslab;
+#if VDN_X8_ABL & 8  // diagnostic build: in-kernel clock of the main loop (MI355X_MICROARCH.md 'DVFS give-back' item 6)
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr std::integral_constant<int, 0> P0{};
   constexpr std::integral_constant<int, 1> P1{};
   constexpr std::integral_constant<int, 2> P2{};
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     if constexpr (X8_L > 4) pro(4, P0);
   }
   // unit 0 has landed when all but the L - 1 newest units have (short K: fewer units were issued, wait for all)
-  if (nunits >= X8_L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X8_L - 1)) : "memory");
+  if (nunits >= X8_L) X8_WAIT_UNITS(X8_L - 1);
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   do {                                                                 \
     reads(PC, rd_slot);                                                \
     ISSUE;                                                             \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");        \
+    X8_WAIT_UNITS(WAIT);                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
     __builtin_amdgcn_s_barrier();                                      \
     __builtin_amdgcn_sched_barrier(0);                                 \
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   } while (0)
   // phase ph of slab s issues unit 4 s + ph + L = phase (ph + L) & 3 of slab s + (ph + L) / 4
 #define X8_ISSUE(PH) issue(s + ((PH) + X8_L) / 4, std::integral_constant<int, ((PH) + X8_L) & 3>{}, wr_slot)
-  constexpr int WFULL = 4 * (X8_L - 1);
+  constexpr int WFULL = X8_L - 1;
   int s = 0;
   // steady state: every phase of slab s issues (the last unit issued is 4 s + 3 + L <= nunits - 1)
   for (; 4 * s + 3 + X8_L <= nunits - 1; ++s) {
@@ -266,9 +280,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       const int inflight = doit ? X8_L - 1 : (left < X8_L - 1 ? (left < 0 ? 0 : left) : X8_L - 1);          \
       reads(PC, rd_slot);                                                                                   \
       if (doit) X8_ISSUE(PH);                                                                               \
-      if (inflight >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                  \
-      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
-      else if (inflight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
+      if (inflight >= 3) X8_WAIT_UNITS(3);                                                                  \
+      else if (inflight == 2) X8_WAIT_UNITS(2);                                                             \
+      else if (inflight == 1) X8_WAIT_UNITS(1);                                                             \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
       __builtin_amdgcn_s_barrier();                                                                         \
@@ -288,13 +302,20 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #undef X8_ISSUE
 #undef X8_PHASE
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
+#if VDN_X8_ABL & 8
+  if (p.splitk_ws && tid == 0 && (blockIdx.x % 37) == 0) {  // a few workgroups report into scratch nothing else reads
+    unsigned long long* dbg = (unsigned long long*)p.splitk_ws + (blockIdx.x / 37) * 2;
+    dbg[0] = __builtin_amdgcn_s_memtime() - st_c0;
+    dbg[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 
   // ---- epilogue: lane = activation row m (lane & 31); registers 4 g .. 4 g + 3 of block (i, j) = output columns
   // 32 j + 8 g + 4 h + {0..3} — or, with PAIR, registers 8 u .. 8 u + 7 = columns 32 j + 16 u + 8 h + {0..7}.
   // Every load (bias, LayerScale, residual) is issued BEFORE the stores it would otherwise queue behind: vmcnt counts loads
   // and stores in one order, so a load behind a store waits for that store's round trip (measured on the first version of
   // this epilogue: 42 us per fc1 tile round against 13 us of store bandwidth).
-  const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+  const int mw = m0 + wm * (X8_BM / 2), nw = n0 + wn * 64;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, o4 = {1.f, 1.f, 1.f, 1.f};
   if constexpr (PAIR) {
     f32x4 bias8[2][2][2];  // [j][u][half]
@@ -308,7 +329,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
           bias8[j][u][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : z4;
         }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -340,8 +361,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     };
     fetch(0, res[0]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i + 1 < 4) fetch(i + 1, res[(i + 1) & 1]);
+    for (int i = 0; i < NI; ++i) {
+      if (i + 1 < NI) fetch(i + 1, res[(i + 1) & 1]);
       const int m = mw + 32 * i + r;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -371,7 +392,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
         // that skip the groups where it would wrap
         const int gb = (g + 2) & 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
           const f32x4 a = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
           const f32x4 b = {acc[i][j][4 * gb], acc[i][j][4 * gb + 1], acc[i][j][4 * gb + 2], acc[i][j][4 * gb + 3]};
           emit4<VDN_F16, STORE>(p, mw + 32 * i + r, n, a, b, bias4[j][g], bias4[j][gb], gam4[j][g]);
@@ -379,17 +400,20 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       }
   }
 }
+#undef X8_WAIT_UNITS
 #undef X8_GLDS
 
-int x8_entry(const vdn_gemm_desc& d, hipStream_t s) {
-  const int tiles = ((d.M + X8_BM - 1) / X8_BM) * ((d.N + X8_BN - 1) / X8_BN);
+template <int BM>
+static int x8_launch(const vdn_gemm_desc& d, hipStream_t s) {
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + X8_BN - 1) / X8_BN);
   const dim3 g(tiles), b(512);
+  constexpr int LDS = X8_NSLOT * x8_unit(BM);
 #define VDN_X8(ST, PAIR)                                                                                               \
   do {                                                                                                                   \
-    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_x8_kernel<ST, PAIR>,                            \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, X8_LDS); /* once */   \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_x8_kernel<ST, PAIR, BM>,                        \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS); /* once */      \
     if (attr != hipSuccess) return -(1000 + (int)attr);                                                                  \
-    hipLaunchKernelGGL((gemm_x8_kernel<ST, PAIR>), g, b, X8_LDS, s, d);                                                  \
+    hipLaunchKernelGGL((gemm_x8_kernel<ST, PAIR, BM>), g, b, LDS, s, d);                                                 \
   } while (0)
   int fl = epi_flavour(d);
   // plane-output flavours store 8 columns (16 bytes) per lane: column counts and strides must keep that aligned
@@ -408,6 +432,17 @@ int x8_entry(const vdn_gemm_desc& d, hipStream_t s) {
 #undef VDN_X8
   VDN_CHECK_LAUNCH();
   return VDN_OK;
+}
+
+// M tile: the one that needs the least tile-row-rounds of the CUs this launch can count on (192-row tiles run 8 % slower
+// per row: 12 instead of 16 MFMAs per phase between the same two barriers, and W is re-read per 192 instead of 256 rows)
+int x8_entry(const vdn_gemm_desc& d, hipStream_t s) {
+  const vdn_gemm_tuning& tu = tuning();
+  const int cus = tu.cus > 0 ? tu.cus : (d.cu_hint > 0 && d.cu_hint <= 256 ? d.cu_hint : 256);
+  const long tn = (d.N + X8_BN - 1) / X8_BN;
+  auto cost = [&](int bm, double f) { const long t = (long)((d.M + bm - 1) / bm) * tn; return (double)((t + cus - 1) / cus) * bm * f; };
+  int bm = tu.force_bm == 192 || tu.force_bm == 256 ? tu.force_bm : (cost(192, 1.08) < cost(256, 1.0) ? 192 : 256);
+  return bm == 192 ? x8_launch<192>(d, s) : x8_launch<256>(d, s);
 }
 
 }  // namespace vdn_gemm_impl
