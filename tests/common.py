@@ -12,7 +12,7 @@ SEED = 1234
 
 
 def schema(which: str, enc: str):
-    with open(os.path.join(GOLD, f"schema_{which}_{enc}.json")) as f:
+    with open(os.path.join(GOLD, f"schema_{which.rstrip('h')}_{enc}.json")) as f:   # "Ah" / "Bh": the same model, heavy weights
         return json.load(f)
 
 
@@ -29,6 +29,8 @@ def synth_sd(which: str, enc: str):
     for k, s in sch["buffers"]:
         b = synth.synth_buffer(SEED, k, tuple(s))   # BatchNorm statistics of the use_bn head ("Af" / "Bf" schemas)
         sd[k] = torch.from_numpy(np.asarray(b)) if b is not None else O.temporal_pe(s[-1], s[1])
+    if which.endswith("h"):   # "Ah" / "Bh": checkpoint-like outliers on top (vdn/synth.heavy_overlay; fixtures *_heavy)
+        synth.heavy_overlay(sd)
     return sd
 
 
@@ -41,6 +43,13 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).double().reshape(-1)
     b = torch.as_tensor(b).double().reshape(-1)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def worst_px(a, b):
+    """max |a - b| relative to max |b|: a handful of badly wrong pixels (a tile tail, a halo) that a whole-map rel-L2 hides."""
+    a = torch.as_tensor(a).double().reshape(-1)
+    b = torch.as_tensor(b).double().reshape(-1)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
 def sample_idx(numel, n=256):

@@ -1,13 +1,14 @@
 """End-to-end parity on the MI355X: the HIP path (through the C-ABI) against the oracle on the same
 seeded inputs and against the committed fixtures from the imported reference.
-Tolerance: 1e-3 relative (rel-L2) on the fp32 depth map — BASELINE.json north_star."""
+Tolerance: 1e-3 relative on the fp32 depth map — BASELINE.json north_star — applied twice: to the rel-L2 of the whole map and
+to the WORST pixel (max |got - ref| <= 1e-3 max |ref|), on the pre-ReLU map as well as on the returned (post-ReLU) one."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from common import GOLD, inputs, rel_l2, sample_idx, stats, synth_sd
+from common import GOLD, inputs, rel_l2, sample_idx, stats, synth_sd, worst_px
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -40,17 +41,18 @@ def _stream_A(name, enc, oracle_steps, which="A"):
         if t in kept:
             e = rel_l2(pre[:, ::sub, ::sub], g[f"pre_{t}"])
             e_post = rel_l2(torch.relu(pre[:, ::sub, ::sub]), np.maximum(g[f"pre_{t}"], 0))
+            w_pre = worst_px(pre[:, ::sub, ::sub], g[f"pre_{t}"])
             mf = model._eng["rt"].hbuf("mem_feat", (B * (H // 14) * (W // 14), model.pretrained.embed_dim)).float().cpu()
             e_mf = rel_l2(mf.reshape(-1)[sample_idx(mf.numel())], g[f"memfeat_samp_{t}"])
-            print(f"[{name}] frame {t}: vs reference fixture pre-ReLU {e:.2e} post-ReLU {e_post:.2e} memory feature {e_mf:.2e}")
+            print(f"[{name}] frame {t}: vs reference fixture pre-ReLU {e:.2e} post-ReLU {e_post:.2e} worst pixel {w_pre:.2e} memory feature {e_mf:.2e}")
             worst = max(worst, e_post)
-            assert e_post < TOL and e < 2 * TOL and e_mf < 2e-3, (name, t, e, e_post, e_mf)
+            assert e_post < TOL and e < TOL and w_pre < TOL and e_mf < 2e-3, (name, t, e, e_post, w_pre, e_mf)
         if t < oracle_steps:
             with torch.no_grad():
                 ref = O.depth_anything_v2_forward(sd, x[t], mem, enc, pre_relu=True)
-            e = rel_l2(torch.relu(pre), torch.relu(ref))
-            print(f"[{name}] frame {t}: vs oracle (full map) post-ReLU {e:.2e}")
-            assert e < TOL
+            e, w_full = rel_l2(torch.relu(pre), torch.relu(ref)), worst_px(pre, ref)
+            print(f"[{name}] frame {t}: vs oracle (full map) post-ReLU {e:.2e}, worst pixel of the full pre-ReLU map {w_full:.2e}")
+            assert e < TOL and w_full < TOL
     return worst
 
 
@@ -121,7 +123,7 @@ def test_stage_fixtures_vit_block_and_dpt_paths(name, enc):
     e["enc"].probe = None
 
 
-def _lanes_against_single_lane_and_fixture(name, enc, B, monkeypatch):
+def _lanes_against_single_lane_and_fixture(name, enc, B, monkeypatch, which="A"):
     """The dispatch bench.py times: a batch of B independent streams dealt to two HIP-stream lanes (own workspace,
     cu_hint = 128, one shared memory-bank ring) for 8 steps — empty bank, filling, full, eviction. Every step must
     equal the single-lane run of the same batch, and batch element 0 carries the fixture's stream, so it must also
@@ -130,7 +132,7 @@ def _lanes_against_single_lane_and_fixture(name, enc, B, monkeypatch):
     _, steps, H, W, sub, _ = [int(v) for v in g["meta"]]
     kept = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("pre_") and not k.startswith("pre_stats"))
     pool = inputs(steps + B - 1, H, W)  # element b sees the fixture's stream delayed by b frames
-    model = _product("A", enc)
+    model = _product(which, enc)
     runs = {}
     for lanes in ("2", "1"):
         monkeypatch.setenv("VDN_STREAMS", lanes)
@@ -194,16 +196,17 @@ def _clip_B(name, enc, use_oracle, which="B"):
             t = int(k.split("_")[1])
             e = rel_l2(pre[t, ::sub, ::sub], g[k])
             e_post = rel_l2(torch.relu(pre[t, ::sub, ::sub]), np.maximum(g[k], 0))
-            print(f"[{name}] frame {t}: vs reference fixture pre-ReLU {e:.2e} post-ReLU {e_post:.2e}")
-            assert e_post < TOL and e < 2 * TOL
+            w_pre = worst_px(pre[t, ::sub, ::sub], g[k])
+            print(f"[{name}] frame {t}: vs reference fixture pre-ReLU {e:.2e} post-ReLU {e_post:.2e} worst pixel {w_pre:.2e}")
+            assert e_post < TOL and e < TOL and w_pre < TOL
     means = np.array([pre[t].mean().item() for t in range(T)])
     assert np.allclose(means, g["pre_stats_all"][:, 0], rtol=5e-3, atol=2e-3)
     if use_oracle:
         with torch.no_grad():
             ref = O.video_depth_anything_forward(synth_sd(which, enc), x, enc, pre_relu=True)[0]
-        e = rel_l2(torch.relu(pre), torch.relu(ref))
-        print(f"[{name}] all {T} frames vs oracle post-ReLU {e:.2e}")
-        assert e < TOL
+        e, w_full = rel_l2(torch.relu(pre), torch.relu(ref)), worst_px(pre, ref)
+        print(f"[{name}] all {T} frames vs oracle post-ReLU {e:.2e}, worst pixel of the full pre-ReLU maps {w_full:.2e}")
+        assert e < TOL and w_full < TOL
 
 
 def test_B_vits_full_window():
@@ -214,6 +217,53 @@ def test_B_use_bn_and_use_clstoken():
     """VideoDepthAnything(use_bn=True, use_clstoken=True): the readout is per frame, so every tap gets it right after the
     encoder (also in the tap cache, the streaming and the sharded drivers); 4-frame clip against the reference fixture."""
     _clip_B("Bf_vits_266", "vits", use_oracle=True, which="Bf")
+
+
+def test_A_vitl_checkpoint_like_weights():
+    """Range test (fixture from the imported reference with vdn/synth.heavy_overlay): residual-stream outlier channels at
+    +-150..550, LayerScale over two decades, attention logits spread over +-170, MLP pre-activations of 1e4 — what a trained
+    DINOv2 checkpoint does to the fp16 planes and the e5m2 cross terms. Frames 0-2 (memory depth 0, 1, 2), ViT-L 518 x 518."""
+    _stream_A("A_vitl_518_heavy", "vitl", oracle_steps=0, which="Ah")
+
+
+def test_A_vitl_checkpoint_like_weights_batch8_two_lanes(monkeypatch):
+    """The same heavy weights at batch 8 (two lanes of M = 5480 rows: the encoder linears run on the 8-bit cross-term kernel,
+    whose e5m2 planes see the 1e4 activations and the +-550 outlier channels)."""
+    _lanes_against_single_lane_and_fixture("A_vitl_518_heavy", "vitl", 8, monkeypatch, which="Ah")
+
+
+def test_fp16_plane_range_is_wide_and_its_overflow_is_loud():
+    """Range of the 16-bit operand planes (INTEGRATION.md 'Range'): hi = RTZ fp16 saturates at 65 504 and lo carries the
+    rest, so an MLP activation of ~1e5 is still represented (parity with the fp32 oracle holds); at ~1e6 the planes
+    overflow and the image / clip drivers raise instead of returning a NaN map."""
+    import vdn
+    from oracle import ref_cpu as O
+    from vdn import synth
+    sd = {k: v.clone() for k, v in synth_sd("Ah", "vits").items()}
+    x = inputs(1, 266, 266)
+    img = np.ascontiguousarray(synth.frames_u8(1234, 1, 266, 266)[0][:, :, ::-1])
+    for gain, ok in ((9.0, True), (100.0, False)):   # the 1e4 unit of block 1 -> ~1e5 (inside) / ~1e6 (outside)
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2["pretrained.blocks.1.mlp.fc1.weight"][77] *= gain
+        sd2["pretrained.blocks.1.mlp.fc1.bias"][77] *= gain
+        model = vdn.DepthAnythingV2(**vdn.MODEL_CONFIGS["vits"])
+        model.load_state_dict(sd2, strict=True)
+        model = model.to("cuda").eval()
+        if ok:
+            got = model.forward(x.cuda(), _pre_relu=True).cpu()
+            with torch.no_grad():
+                ref = O.depth_anything_v2_forward(sd2, x, O.MemoryState(6), "vits", pre_relu=True)
+            e, w = rel_l2(got, ref), worst_px(got, ref)
+            print(f"[range] MLP activations ~1e5 (hi plane saturated, lo carries the rest): rel-L2 {e:.2e}, worst pixel {w:.2e}")
+            assert e < TOL and w < TOL
+            assert np.isfinite(model.infer_image(img, 266)).all()
+        else:
+            with pytest.raises(FloatingPointError, match="fp16 range"):
+                model.infer_image(img, 266)
+
+
+def test_B_vits_checkpoint_like_weights():
+    _clip_B("B_vits_518_heavy", "vits", use_oracle=True, which="Bh")
 
 
 def test_B_vits_nonsquare_short_clip():

@@ -93,6 +93,13 @@ def test_oracle_B_vits_nonsquare():
     _run_B("B_vits_392x518", "vits")
 
 
+def test_oracle_checkpoint_like_weights():
+    """The heavy fixtures (vdn/synth.heavy_overlay: outlier channels, LayerScale over two decades, peaked heads, 1e4 MLP
+    pre-activations): the oracle stays on the imported reference there too (ViT-S clip in full, ViT-L stream frame 0)."""
+    _run_B("B_vits_518_heavy", "vits", which="Bh")
+    _run_A("A_vitl_518_heavy", "vitl", check_steps=[0], which="Ah")
+
+
 def test_oracle_A_vitl():
     _run_A("A_vitl_518", "vitl", check_steps=[0, 1])  # S = 0 and the first cross-attention over a stored frame
 

@@ -65,7 +65,7 @@ def install_shims():
     sys.path.insert(0, REF)
 
 
-def load_synth(model: torch.nn.Module, fast: bool = False):
+def load_synth(model: torch.nn.Module, fast: bool = False, heavy: bool = False):
     """fast: torch's CPU generator instead of the portable counter hash (ViT-g has 1.1 G parameters: minutes vs seconds);
     the same torch build runs here and on the GPU box, tests/common.synth_sd takes the same branch for "vitg"."""
     from vdn import synth
@@ -81,6 +81,9 @@ def load_synth(model: torch.nn.Module, fast: bool = False):
         b = synth.synth_buffer(SEED, k, tuple(v.shape))
         if b is not None:
             sd[k] = torch.from_numpy(np.asarray(b))
+    if heavy:   # checkpoint-like outliers (vdn/synth.heavy_overlay): massive activations, LayerScale spread, peaked heads
+        sd = {k: v.clone() for k, v in sd.items()}
+        synth.heavy_overlay(sd)
     model.load_state_dict(sd, strict=True)
     return {k: v.detach().clone() for k, v in model.state_dict().items()}, shapes
 
@@ -132,13 +135,14 @@ class StageHooks:
         sc.output_conv1.register_forward_hook(lambda m, i, o: self.v.update(oc1=o.detach().permute(0, 2, 3, 1).contiguous()))
 
 
-def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str, stages: bool = False, flags: dict = None):
+def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, name: str, stages: bool = False, flags: dict = None,
+          heavy: bool = False):
     from depth_anything_v2.depth_anything_v2 import DepthAnythingV2
     from oracle import ref_cpu as O
     cfg = dict(O.MODEL_CONFIGS[enc], **(flags or {}))
     torch.manual_seed(0)
     model = DepthAnythingV2(**cfg).eval()
-    sd, shapes = load_synth(model, fast=(enc == "vitg"))
+    sd, shapes = load_synth(model, fast=(enc == "vitg"), heavy=heavy)
     with open(os.path.join(GOLD, f"schema_A{'f' if flags else ''}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
@@ -185,17 +189,17 @@ def gen_A(enc: str, H: int, W: int, B: int, steps: int, keep: list, sub: int, na
             idx, val = samples(mf_ref)
             out[f"memfeat_stats_{t}"] = stats(mf_ref)
             out[f"memfeat_samp_{t}"] = val
-    assert worst <= 1e-5, worst
+    assert worst <= (1e-4 if heavy else 1e-5), worst   # heavy: fp32 itself carries ~1e-5 on such weights (two summation orders)
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
-def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str, flags: dict = None):
+def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str, flags: dict = None, heavy: bool = False):
     from video_depth_anything.video_depth import VideoDepthAnything
     from oracle import ref_cpu as O
     cfg = dict(O.MODEL_CONFIGS[enc], **(flags or {}))
     torch.manual_seed(0)
     model = VideoDepthAnything(**cfg).eval()
-    sd, shapes = load_synth(model)
+    sd, shapes = load_synth(model, heavy=heavy)
     with open(os.path.join(GOLD, f"schema_B{'f' if flags else ''}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
@@ -225,11 +229,11 @@ def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str, fla
         o2 = o.permute(0, 2, 1, 3, 4).flatten(0, 1)
         em = relerr(tr[names[i]], o2)
         print(f"    motion_module[{i}] out {tuple(o2.shape)} std {o2.std():.3f} oracle rel err {em:.2e}")
-        assert em <= 1e-5
+        assert em <= (1e-4 if heavy else 1e-5)
         idx, val = samples(o2)
         out[f"mm{i}_stats"] = stats(o2)
         out[f"mm{i}_samp"] = val
-    assert max(e, e2) <= 1e-5
+    assert max(e, e2) <= (1e-4 if heavy else 1e-5)
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 
@@ -431,6 +435,9 @@ JOBS = {
     "B_vitl_518_T32": lambda: gen_B("vitl", 518, 518, 32, [0, 13, 31], 4, "B_vitl_518_T32"),
     # BASELINE configs[4]: v5 refiner, ViT-L, num_frames = 64 on a [1, 64, 1024, 1024] clip (the network runs at 224 x 224)
     "R5_vitl_T64": lambda: gen_refiner(5, "vitl", 64, 1024, 1024, "R5_vitl_T64", num_frames=64, sub=16),
+    # checkpoint-like weights (vdn/synth.heavy_overlay): outlier channels, LayerScale over two decades, peaked heads, 1e3-1e4 MLP units
+    "A_vitl_518_heavy": lambda: gen_A("vitl", 518, 518, 1, 3, [0, 1, 2], 4, "A_vitl_518_heavy", heavy=True),
+    "B_vits_518_heavy": lambda: gen_B("vits", 518, 518, 4, [0, 3], 2, "B_vits_518_heavy", heavy=True),
     "R5_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5_vits"),
     "R5f_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5f_vits", flags=dict(use_bn=True, use_clstoken=True)),
     "R4_vits": lambda: gen_refiner(4, "vits", 3, 126, 168, "R4_vits"),

@@ -187,6 +187,8 @@ class DepthAnythingV2(_EngineOwner):
             out = torch.empty((1, h, w), dtype=torch.float32, device=rt.device)
             rt.upsample_f32(depth.contiguous(), out, 1, depth.shape[-2], depth.shape[-1], h, w)
             depth = out
+        from .util import check_finite
+        check_finite(depth, "infer_image")
         return depth[0].cpu().numpy()
 
     def image2tensor(self, raw_image: np.ndarray, input_size: int = 518):

@@ -186,3 +186,44 @@ def fast_state_dict(named_shapes, seed: int = 1234):
 def synth_state_dict(named_shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 1234) -> Dict[str, np.ndarray]:
     """named_shapes: (key, shape) for every *parameter* (buffers keep their module-computed values)."""
     return {k: synth_param(seed, k, tuple(s)) for k, s in named_shapes}
+
+
+# ---------------------------------------------------------------------------------------------
+# "checkpoint-like" overlay (fixtures *_heavy): what a trained DINOv2 / DPT checkpoint has and the O(1) synthetic
+# weights above do not — a few residual-stream OUTLIER channels two orders of magnitude above the rest at a handful of
+# tokens (DINOv2's massive activations), LayerScale factors spread over 1e-2 .. 1, attention heads whose logits spread
+# over +-40 (near one-hot softmax rows), and MLP hidden units whose pre-activations reach 1e3 .. 1e4.
+# Pure index arithmetic on a finished state dict (numpy arrays or torch tensors, modified in place): the GPU box
+# rebuilds exactly the weights the fixtures were made with.
+def heavy_overlay(sd, prefix: str = "pretrained."):
+    def get(k):
+        return sd[prefix + k]
+
+    C = int(get("pos_embed").shape[-1])
+    P = int(get("pos_embed").shape[1]) - 1
+    depth = 1 + max(int(k.split(".")[-3]) for k in sd if k.startswith(prefix + "blocks.") and k.endswith(".ls1.gamma"))
+    # (1) outlier channels of the residual stream at the cls token and three patch tokens
+    chans = [7, C // 3 + 5, C - 11]
+    toks = [0, 18, 1 + P // 2, P]
+    pe = get("pos_embed")
+    for i, c in enumerate(chans):
+        for j, t in enumerate(toks):
+            pe[0, t, c] = (150.0 + 25.0 * i) * (1.0 if (i + j) % 2 == 0 else -1.0)
+    # (2) LayerScale spread over two decades (golden-ratio sequence: deterministic, equidistributed)
+    for L in range(depth):
+        for n, ph in (("ls1", 0.0), ("ls2", 0.37)):
+            g = get(f"blocks.{L}.{n}.gamma")
+            for c in range(C):
+                u = (c * 0.6180339887498949 + ph + 0.11 * L) % 1.0
+                g[c] = 10.0 ** (-2.0 + 2.0 * u)
+    # (3) peaked attention: head 0 of two blocks gets q and k rows x5 (logits x25: spread >= 40)
+    for L in (2 % depth, depth - 2):
+        w, b = get(f"blocks.{L}.attn.qkv.weight"), get(f"blocks.{L}.attn.qkv.bias")
+        w[0:64] *= 5.0; b[0:64] *= 5.0
+        w[C:C + 64] *= 5.0; b[C:C + 64] *= 5.0
+    # (4) MLP hidden units with pre-activations of 1e3 .. 1e4 (their fc2 columns then write massive values into the stream)
+    for L, units in ((1, ((3, 1000.0), (77, 3000.0))), (depth // 2, ((500, 1000.0),))):
+        w1, b1 = get(f"blocks.{L}.mlp.fc1.weight"), get(f"blocks.{L}.mlp.fc1.bias")
+        for j, gain in units:
+            w1[j] *= gain; b1[j] *= gain
+    return sd

@@ -101,6 +101,17 @@ def stitch(depth_list: List[np.ndarray], org_len: int) -> np.ndarray:
 _HOST_OUT = {}   # (shape, dtype) -> (pinned tensor, weakref to the ndarray handed out last time)
 
 
+def check_finite(t: torch.Tensor, what: str):
+    """Loud range check of a driver's result before it leaves the device (one reduction next to the copy that synchronises
+    anyway). 16-bit operand planes are fp16: an activation beyond +-1.3e5 (hi saturates at 65 504, lo carries the next
+    65 504) — +-5.7e4 on the 8-bit cross-term path, whose e5m2 planes top out there — turns into inf / NaN and reaches the
+    depth map; no checkpoint the reference ships comes near (INTEGRATION.md 'Range'). VDN_PRECISION=bf16x3 has fp32's range."""
+    if not bool(torch.isfinite(t).all()):
+        raise FloatingPointError(
+            f"{what}: non-finite depth values — an activation left the fp16 range of the operand planes (|x| >= 1.3e5, or 5.7e4 on "
+            f"the 8-bit cross-term path). Re-run with VDN_PRECISION=bf16x3 (fp32 range); see INTEGRATION.md 'Range'.")
+
+
 def to_host(t: torch.Tensor) -> np.ndarray:
     """The clip drivers' single device-to-host copy, through PINNED memory: a pageable `.cpu()` of the 275 MB result of a
     256-frame clip runs at 6-8 GB/s (35-45 ms, measured on the MI355X box), the same copy into a pinned buffer at 55 GB/s

@@ -94,8 +94,9 @@ class VideoDepthAnything(_EngineOwner):
             input_size = int(input_size * 1.777 / ratio)
             input_size = round(input_size / 14) * 14
         x = self.preprocess_frames(frame[None], input_size)[None]
-        d = self.stream_step(x)
-        return self.resize_depth(d[None], fh, fw)[0].cpu().numpy()
+        d = self.resize_depth(self.stream_step(x)[None], fh, fw)
+        util.check_finite(d, "infer_video_depth_one")
+        return d[0].cpu().numpy()
 
     @torch.no_grad()
     def forward_sharded(self, x_local: torch.Tensor, group=None, _pre_relu: bool = False) -> torch.Tensor:
@@ -185,7 +186,9 @@ class VideoDepthAnything(_EngineOwner):
         st = DeviceStitcher(rt, len(table), fh, fw)
         for d in self.window_depths(net_in, table):
             st.push(self.resize_depth(d, fh, fw))  # [32,fh,fw], stays on the device
-        return util.to_host(st.result(n)), target_fps  # the clip's only device-to-host copy (pinned buffer)
+        res = st.result(n)
+        util.check_finite(res, "infer_video_depth")
+        return util.to_host(res), target_fps  # the clip's only device-to-host copy (pinned buffer)
 
     # bytes of encoder taps one frame keeps in the clip-level cache: 4 taps x P tokens x C channels x 16-bit planes
     def _tap_bytes_per_frame(self, H: int, W: int) -> int:
