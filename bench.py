@@ -36,13 +36,16 @@ sys.path.insert(0, os.path.join(ROOT, "video-depth-normal-v2_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_F16 = 2500.0  # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+# what a register-only loop of v_mfma_f32_32x32x16_f16 sustains on this part under its power-managed clock (SURVEY.md §8d asks
+# for both): tools/micro/mfma_scale_probe.hip, profiles/r02_mfma_scale_probe.log
+PEAK_MEASURED_TFLOPS_F16 = 1808.0
 
 
 def _pmc_traffic(prec_name):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).
     Not measured by this process: the JSON names the file in `traffic_source`."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -52,6 +55,26 @@ def _pmc_traffic(prec_name):
         except (OSError, ValueError):
             continue
     return None, None
+
+
+def _attn_mfma_busy():
+    """Matrix-pipe busy share of the attention kernel from the newest committed PMC passes (tools/pmc_attn.sh over
+    tools/attn_bench.py): mean of SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over SQ_BUSY_CYCLES / 32 (north star: >= 0.40).
+    Not measured by this process."""
+    import re
+    for name in ("r03_pmc_attention.txt", "r02_pmc_attention_final.txt"):
+        try:
+            txt = open(os.path.join(ROOT, "profiles", name)).read()
+        except OSError:
+            continue
+        vals = {}
+        for m in re.finditer(r"grid\s+(\d+)\s+(SQ_VALU_MFMA_BUSY_CYCLES|SQ_BUSY_CYCLES)\s+n=\s*\d+\s+mean\s+([0-9.]+)", txt):
+            vals.setdefault(int(m.group(1)), {})[m.group(2)] = float(m.group(3))
+        fr = [(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["SQ_BUSY_CYCLES"] / 32.0) for v in vals.values() if len(v) == 2 and v["SQ_BUSY_CYCLES"] > 0]
+        if fr:
+            return {"value": round(sum(fr) / len(fr), 3), "source": "profiles/" + name,
+                    "definition": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 over SQ_BUSY_CYCLES / 32, rocprofv3 --pmc (separate passes), mean over the bench shapes"}
+    return None
 
 
 def _free_port() -> int:
@@ -147,6 +170,17 @@ class _StubVideoModel:
         k, c, H, W = x.shape
         return [x.permute(0, 2, 3, 1).reshape(k * H * W, c).contiguous()], H * W, (H, W)
 
+    # chunked form of encode_frames (vdn/dist.py TapExchange: a chunk's taps travel while the next chunk is encoded)
+    def tap_planes(self, x):
+        import torch
+        k, c, H, W = x.shape
+        self._planes = [torch.empty((k * H * W, c), dtype=torch.float32)]
+        return self._planes, H * W, (H, W)
+
+    def encode_into(self, x, planes, first):
+        k, c, H, W = x.shape
+        planes[0][first * H * W:(first + k) * H * W].copy_(x.permute(0, 2, 3, 1).reshape(k * H * W, c))
+
     def head_from_planes(self, planes, Tl, T, hw, group=None):
         from vdn.dist import FrameShardExchange, shard_core
         H, W = hw
@@ -186,11 +220,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # fail fast: a collective that does not complete within VDN_DIST_TIMEOUT_S (default 300 s) raises instead of hanging
+        # the node; main() then exits non-zero and the launcher tears the other ranks down
+        tmo = datetime.timedelta(seconds=int(os.environ.get("VDN_DIST_TIMEOUT_S", "300")))
         if a.stub or a.shared_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     n_gpus = world
     dev = torch.device("cpu") if a.stub else torch.device("cuda", local)
@@ -273,16 +312,26 @@ def main():
         e = model._engines()
         return [e["rt"]] + [ln["rt"] for ln in (getattr(model, "_lanes", None) or [])[1:]]
 
+    step_ms = []   # per-step HIP-event durations of the last timed() call
+
     def timed(nsteps, events, fn=None):
         fn = fn or step
         for rt in runtimes():
             rt.timing = [] if events else None
         sync_all()
+        marks = []
         t0 = time.perf_counter()
         for _ in range(nsteps):
+            if not a.stub:   # HIP events on the stream the step is issued on (lanes fork from and join into it)
+                s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_ev.record()
             fn()
+            if not a.stub:
+                e_ev.record()
+                marks.append((s_ev, e_ev))
         sync_all()
         dt = time.perf_counter() - t0
+        step_ms[:] = [s_.elapsed_time(e_) for s_, e_ in marks]
         ev = []
         for rt in runtimes():
             ev += rt.timing or []
@@ -305,6 +354,7 @@ def main():
     # issued on ONE lane right after it (same memory bank: the lanes share one ring, still full).
     want_events = (not a.no_kernel_events) and not a.stub
     dt, ev = timed(a.steps, want_events and lanes == 1)
+    step_ms_main = list(step_ms)
     strong = a.workload == "video"
     fps = frames_per_step * a.steps * (1 if strong else n_gpus) / dt
     dt1 = None
@@ -333,6 +383,9 @@ def main():
                   ("depth frames/sec at 518x518, ViT-L" if enc == "vitl" else f"depth frames/sec at 518x518, {enc}"),
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+        # `value` / ms_per_step: wall clock over the K steps between two barrier + synchronize pairs (the contract; includes the
+        # host's launch work). ms_per_step_event_median: HIP-event pair around every step on its stream, median
+        "ms_per_step_event_median": round(statistics.median(step_ms_main), 3) if step_ms_main else None,
         "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": prec_name, "data": "synthetic",
         "config": {"workload": workload, "frames_per_step_per_gpu": frames_per_step if not strong else frames_per_step / n_gpus,
@@ -357,17 +410,31 @@ def main():
         C = vdn.modules.ENCODERS[enc]["dim"]
         lin = [(s.elapsed_time(e), fl) for (tag, s, e, fl) in ev if tag == "enc_linear"]
         nprod = 3 if prec_name.endswith("x3") else 1
+        enc_eng = model._engines()["enc"]
+        rows = frames_per_step * ((H // 14) * (W // 14) + 1)   # the events come from a single-lane pass: the whole batch per launch
+        x8 = bool(getattr(enc_eng, "x8", False)) and rows >= 4096 and prec_name == "f16x3"
         if lin:
             tot_ms, tot_fl = sum(t for t, _ in lin), sum(f for _, f in lin)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             # the PMC passes (tools/pmc_traffic.sh) ran the batch-8 stream workload: their per-launch bytes describe that launch size only
             traffic, traffic_src = _pmc_traffic(prec_name) if (a.workload == "stream" and a.batch == 8 and enc == "vitl") else (None, None)
             out["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_x3_p8_kernel<256x256x32> (fc1) / gemm_x3_big_kernel<192x256x32> (qkv, proj, fc2): the 4 encoder linears" if nprod == 3 else "gemm_kernel<128x128x64> on the 4 encoder linears (qkv, proj, fc1, fc2)",
+                "bound": "mfma",
+                "kernel": ("gemm_x8_kernel<256|192 x 256 x 64> on the 4 encoder linears (qkv, proj, fc1, fc2): A_hi W_hi^T on fp16 MFMAs + the two "
+                           "split-precision cross terms on the block-scaled e5m2 MFMA, K-tile-major planes" if x8 else
+                           "gemm_x3_p8_kernel<256x256x32> (fc1) / gemm_x3_big_kernel<192x256x32> (qkv, proj, fc2): the 4 encoder linears" if nprod == 3
+                           else "gemm_kernel<128x128x64> on the 4 encoder linears (qkv, proj, fc1, fc2)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
+                "peak_measured": PEAK_MEASURED_TFLOPS_F16, "frac_of_measured": round(ach / PEAK_MEASURED_TFLOPS_F16, 4),
+                "peak_measured_source": "profiles/r02_mfma_scale_probe.log (register-only fp16 32x32x16 loop on the box: what the power-managed clock sustains)",
                 "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(lin),
-                "avg_launch_ms": round(tot_ms / len(lin), 4), "algorithmic_gflop_per_launch": round(tot_fl / len(lin) / 1e9, 2),
-                "mfma_products_per_term": nprod, "executed_frac": round(nprod * ach / PEAK_TFLOPS_F16, 4)}
+                "avg_launch_ms": round(tot_ms / len(lin), 4), "algorithmic_gflop_per_launch": round(tot_fl / len(lin) / 1e9, 2)}
+            # matrix-pipe work actually issued per algorithmic product: 3 fp16 products (x3), or 1 fp16 + 2 e5m2 products that the
+            # scaled MFMA runs at 2.32x the fp16 rate (measured, same probe) = 1.86 fp16-product equivalents
+            eq = (1.0 + 2.0 / 2.32) if x8 else float(nprod)
+            out["roofline"].update({"mfma_products_per_term": ("1 fp16 + 2 e5m2 (block-scaled, 2.32x rate)" if x8 else nprod),
+                                    "fp16_product_equivalents": round(eq, 2), "executed_frac": round(eq * ach / PEAK_TFLOPS_F16, 4),
+                                    "executed_frac_of_measured": round(eq * ach / PEAK_MEASURED_TFLOPS_F16, 4)})
             if dt1 is not None:
                 out["roofline"]["measured_in"] = (
                     "single-lane pass of %d steps run right after the timed region (%.1f frames/s, same full memory bank); the "
@@ -379,8 +446,28 @@ def main():
             tf = tot_fl / (tot_ms * 1e-3) / 1e12
             out["attention_kernel"] = {"avg_launch_ms": round(tot_ms / len(att), 4), "achieved_tflops": round(tf, 2),
                                        "frac_of_mfma_peak": round(tf / PEAK_TFLOPS_F16, 4),
+                                       "mfma_busy_frac": _attn_mfma_busy(),
                                        "note": "algorithmic flops (4 nq nk 64 per head) / HIP-event time; the kernel issues 1 fp16 + 2 "
                                                "block-scaled 8-bit products for QK^T and attention_pv_products for P V"}
+
+    # ---------------- where an N-GPU step spends its time: one more DIAGNOSTIC step with the device synchronised at every phase
+    # boundary (not the timed region), seconds per phase as MAX over ranks, bytes as SUM over ranks
+    if strong and dist is not None:
+        st = {}
+        infer_video_depth_sharded(model, video, 24, input_size=H, all_ranks=False, stats=st)
+        keys = ["preprocess", "encode", "tap_exchange_wait", "heads", "gather", "stitch", "to_host"]
+        bkeys = ["bytes_taps_sent", "bytes_temporal_a2a_sent", "bytes_gather_sent"]
+        cdev = "cpu" if (a.shared_gpu or a.stub) else dev
+        tv = torch.tensor([st.get(k, 0.0) for k in keys], dtype=torch.float64, device=cdev)
+        bv = torch.tensor([float(st.get(k, 0)) for k in bkeys], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        dist.all_reduce(bv, op=dist.ReduceOp.SUM)
+        out["phases"] = {"seconds_max_over_ranks": {k: round(float(v), 4) for k, v in zip(keys, tv.tolist())},
+                         "bytes_sum_over_ranks": {k: int(v) for k, v in zip(bkeys, bv.tolist())},
+                         "encoder_chunk_frames": int(os.environ.get("VDN_ENC_CHUNK", "8")),
+                         "note": "one diagnostic step after the timed region, device synchronised at every phase boundary (the timed "
+                                 "steps overlap the tap exchange with the encoder and do not synchronise); tap_exchange_wait = what "
+                                 "was left of the exchange after the last encoder chunk"}
 
     # ---------------- the same workload on ONE GPU (rank 0 alone) next to the N-GPU number of the strong-scaling run
     if strong and dist is not None and not a.stub:
@@ -464,4 +551,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:   # a rank that fails (collective timeout, HIP error) must take the job down, not leave peers waiting
+        import traceback
+        traceback.print_exc()
+        print(f"bench.py: rank {os.environ.get('RANK', '0')} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        os._exit(1)

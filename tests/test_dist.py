@@ -84,7 +84,12 @@ def _worker_hybrid(rank, world, port, out, n, staged=False):
     vdn.dist._FORCE_STAGING = staged   # the byte staging a gloo group applies to device tensors (shared-GPU rehearsal)
     frames = synth.frames_u8(7, n, 28, 42)
     m = bench._StubVideoModel()
-    d, fps = infer_video_depth_sharded(m, frames, 30, input_size=28, all_ranks=True)
+    os.environ["VDN_ENC_CHUNK"] = "3"   # several encoder chunks per rank, the last one ragged: every chunk's taps go out on their own
+    st = {}
+    d, fps = infer_video_depth_sharded(m, frames, 30, input_size=28, all_ranks=True, stats=st)
+    assert all(k in st for k in ("preprocess", "encode", "tap_exchange_wait", "heads", "gather", "stitch", "bytes_taps_sent",
+                                 "bytes_temporal_a2a_sent", "bytes_gather_sent")), st
+    os.environ["VDN_ENC_CHUNK"] = "64"  # one chunk
     d0, _ = infer_video_depth_sharded(m, frames, 30, input_size=28, all_ranks=False)
     # the same clip through the per-job path (whole forward / forward_sharded per window, no tap exchange)
     d1, _ = infer_video_depth_sharded(m, frames, 30, input_size=28, forward=m.forward, forward_sharded=m.forward_sharded)
@@ -177,6 +182,9 @@ def test_bench_gpus_2_spawns_two_ranks():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and j["scaling"] == "strong"
     assert j["config"]["schedule"]["frame_sharded_jobs"] == [[2, 0, 2]] and j["value"] > 0
+    ph = j["phases"]   # the first 8-GPU run must be attributable: per-phase seconds (max over ranks) and bytes exchanged
+    assert set(ph["seconds_max_over_ranks"]) >= {"encode", "tap_exchange_wait", "heads", "gather", "stitch"}
+    assert ph["bytes_sum_over_ranks"]["bytes_taps_sent"] > 0 and ph["bytes_sum_over_ranks"]["bytes_gather_sent"] > 0
     env["WORLD_SIZE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], env=env,
                        capture_output=True, text=True, timeout=120)

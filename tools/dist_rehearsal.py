@@ -49,7 +49,8 @@ def main():
     from vdn.dist import infer_video_depth_sharded, plan_schedule
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
+    import datetime
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("VDN_DIST_TIMEOUT_S", "300"))))
     P, r = dist.get_world_size(), dist.get_rank()
     assert P == a.ranks
     torch.cuda.set_device(0)

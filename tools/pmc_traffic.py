@@ -25,7 +25,7 @@ for key in sorted(F, key=lambda k: -sum(F[k])):
     rows.append((key[0], key[1], len(f), 2 * 1024 * sum(f) / len(f), 1024 * sum(w) / len(w)))
 # encoder-linear launches (single lane, batch 8: M = 8*1370): the plain-A 8-wave kernels at 232 (proj, fc2),
 # 688 (fc1, BM 256) and 696 (qkv) workgroups of 512 threads
-enc = [r for r in rows if (r[0].startswith("gemm_x3_big_kernel<0, 0,") or r[0].startswith("gemm_x3_p8_kernel<0, 0,"))
+enc = [r for r in rows if (r[0].startswith("gemm_x3_big_kernel<0, 0,") or r[0].startswith("gemm_x3_p8_kernel<0, 0,") or r[0].startswith("gemm_x8_kernel<"))
        and r[1] in (232 * 512, 688 * 512, 696 * 512, 928 * 512, 516 * 512, 172 * 512)]
 n = sum(r[2] for r in enc)
 rd = sum(r[3] * r[2] for r in enc) / max(n, 1)

@@ -65,15 +65,26 @@ def _unbytes(dst: torch.Tensor, host: torch.Tensor):
     dst.copy_(host.to(dst.device).view(dst.dtype).reshape(dst.shape))
 
 
-def all_to_all(recv: torch.Tensor, send: torch.Tensor, out_split=None, in_split=None, group=None):
-    """dist.all_to_all_single over dim 0 (row counts in the split lists)."""
+COUNTERS = {"a2a_bytes_sent": 0, "a2a_calls": 0}   # payload this rank handed to all_to_all (diagnostics: bench.py's phase report)
+
+
+def all_to_all(recv: torch.Tensor, send: torch.Tensor, out_split=None, in_split=None, group=None, async_op: bool = False):
+    """dist.all_to_all_single over dim 0 (row counts in the split lists). async_op (RCCL only): the collective is enqueued
+    on the communicator's own stream behind the work already on the current stream and a handle is returned; the caller's
+    later kernels run beside it and `handle.wait()` orders the current stream behind the exchange. The host-staged gloo
+    path is synchronous and returns None."""
+    COUNTERS["a2a_bytes_sent"] += send.numel() * send.element_size()
+    COUNTERS["a2a_calls"] += 1
     if not _staged(send, group):
+        if async_op and dist.get_backend(group) != "gloo":
+            return dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group, async_op=True)
         dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
-        return
+        return None
     hs = _bytes(send)
     hr = torch.empty((recv.shape[0], _row_bytes(recv)), dtype=torch.uint8)
     dist.all_to_all_single(hr, hs, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
     _unbytes(recv, hr)
+    return None
 
 
 def gather_to(t: torch.Tensor, parts, dst: int = 0, group=None):
@@ -135,13 +146,19 @@ def schedule_rounds(n_windows: int, nranks: int) -> float:
 
 
 _GROUPS: Dict[Tuple[int, int], object] = {}
+_GROUPS_OF = [None]   # the default process group the cached subgroups belong to
 
 
 def _subgroups(nranks: int, g: int):
     """Process groups of `g` consecutive ranks (aligned blocks). Collective: every rank creates every group,
-    in the same order (torch.distributed.new_group contract)."""
+    in the same order (torch.distributed.new_group contract). Cached per default process group: after
+    destroy_process_group / init_process_group the cache is dropped (its groups died with the old world)."""
     if g == 1 or nranks == 1:
         return None
+    cur = dist.distributed_c10d._get_default_group()
+    if _GROUPS_OF[0] is not cur:
+        _GROUPS.clear()
+        _GROUPS_OF[0] = cur
     key = (nranks, g)
     if key not in _GROUPS:
         _GROUPS[key] = [dist.new_group(list(range(b, b + g))) for b in range(0, nranks - g + 1, g)]
@@ -181,29 +198,75 @@ def exchange_taps(planes: List[torch.Tensor], rows_per_frame: int, local: List[i
     """One all-to-all (variable splits) per plane: every rank hands each peer the tap rows of the frames that peer's
     head jobs read (`send[r][dst]`) — the RCCL exchange of per-frame feature memory over xGMI. Returns
     (received planes, {frame: first row}). planes: [len(local) * rows_per_frame, C] tensors of this rank's frames."""
-    P = len(send)
-    lpos = {f: i for i, f in enumerate(local)}
-    idx_out = [f for dst in range(P) for f in send[r][dst]]
-    in_split = [len(send[r][dst]) * rows_per_frame for dst in range(P)]
-    out_split = [len(send[src][r]) * rows_per_frame for src in range(P)]
-    where, row = {}, 0
-    for src in range(P):
-        for f in send[src][r]:
-            where[f] = row
-            row += rows_per_frame
-    got = []
-    for pl in planes:
-        C = pl.shape[-1]
-        sbuf = pl.new_empty((sum(in_split), C))
-        for i, f in enumerate(idx_out):
-            sbuf[i * rows_per_frame:(i + 1) * rows_per_frame].copy_(pl[lpos[f] * rows_per_frame:(lpos[f] + 1) * rows_per_frame])
-        rbuf = pl.new_empty((sum(out_split), C))
-        if P > 1:
-            all_to_all(rbuf, sbuf, out_split, in_split, group)
-        else:
-            rbuf.copy_(sbuf)
-        got.append(rbuf)
-    return got, where
+    ex = TapExchange(planes, rows_per_frame, local, send, r, chunk=max(1, len(local)), group=group)
+    ex.send_chunk(0)
+    return ex.finish()
+
+
+class TapExchange:
+    """The encoder-tap exchange in CHUNKS of `chunk` local frames, so that it runs behind the encoder: the driver encodes
+    chunk c, calls `send_chunk(c)` — one variable-split all-to-all per plane, asynchronous under RCCL: it waits for the
+    encoder kernels already on the stream and runs beside the next chunk's — and `finish()` waits for all of them. Every
+    rank issues the same number of chunks (`nchunks`: from the largest local share; a rank without frames in a chunk
+    sends nothing but still takes part). Send buffers are built with ONE index_select per plane and chunk; the rows
+    received from every (chunk, source) land in one buffer per plane, `where[frame]` = first row."""
+
+    def __init__(self, planes, rows_per_frame: int, local: List[int], send, r: int, chunk: int, group=None):
+        self.planes, self.n, self.local, self.r, self.group = planes, rows_per_frame, local, r, group
+        P = self.P = len(send)
+        self.chunk = chunk
+        per = max(len(f) for f in _owned(send, P))
+        self.nchunks = max(1, (per + chunk - 1) // chunk)
+        owned = _owned(send, P)                       # frames each rank encodes, in its local (ascending) order
+        cpos = [{f: i // chunk for i, f in enumerate(owned[q])} for q in range(P)]
+        # rows this rank receives: chunk-major, then source rank, then the order of send[src][r]
+        self.where, self.out_split, self.in_split, self.idx = {}, [], [], []
+        row = 0
+        lpos = {f: i for i, f in enumerate(local)}
+        dev = planes[0].device
+        self.recv_off = []
+        for c in range(self.nchunks):
+            self.recv_off.append(row)
+            osp = []
+            for src in range(P):
+                fr = [f for f in send[src][r] if cpos[src][f] == c]
+                for f in fr:
+                    self.where[f] = row
+                    row += rows_per_frame
+                osp.append(len(fr) * rows_per_frame)
+            self.out_split.append(osp)
+            mine = [[f for f in send[r][dst] if cpos[r][f] == c] for dst in range(P)]
+            self.in_split.append([len(m) * rows_per_frame for m in mine])
+            rows = [lpos[f] * rows_per_frame + k for m in mine for f in m for k in range(rows_per_frame)]
+            self.idx.append(torch.tensor(rows, dtype=torch.long, device=dev))
+        self.recv = [pl.new_empty((row, pl.shape[-1])) for pl in planes]
+        self.handles = []
+        self.bytes_sent = 0
+
+    def send_chunk(self, c: int):
+        for pl, rb in zip(self.planes, self.recv):
+            sbuf = pl.index_select(0, self.idx[c])
+            end = self.recv_off[c] + sum(self.out_split[c])
+            dst = rb[self.recv_off[c]:end]
+            self.bytes_sent += (sum(self.in_split[c]) - self.in_split[c][self.r]) * _row_bytes(pl)
+            if self.P > 1:
+                h = all_to_all(dst, sbuf, self.out_split[c], self.in_split[c], self.group, async_op=True)
+                if h is not None:
+                    self.handles.append((h, sbuf))   # keep the send buffer alive until the collective has run
+            else:
+                dst.copy_(sbuf)
+
+    def finish(self):
+        for h, _ in self.handles:
+            h.wait()
+        self.handles = []
+        return self.recv, self.where
+
+
+def _owned(send, P: int) -> List[List[int]]:
+    """Frames each rank encodes (ascending): the union of what it sends to anyone — every encoded frame is needed by at
+    least one head job — as tap_exchange_plan's `local`."""
+    return [sorted({f for dst in range(P) for f in send[src][dst]}) for src in range(P)]
 
 
 def _slot_rows(planes: List[torch.Tensor], where, slots: Sequence[int], rows_per_frame: int) -> List[torch.Tensor]:
@@ -227,7 +290,7 @@ def _slot_rows(planes: List[torch.Tensor], where, slots: Sequence[int], rows_per
 
 def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size: int = 518, group=None,
                               forward: Optional[Callable] = None, forward_sharded: Optional[Callable] = None,
-                              all_ranks: bool = True):
+                              all_ranks: bool = True, stats: Optional[dict] = None):
     """Multi-GPU twin of VideoDepthAnything.infer_video_depth (video_depth.py:67-156) over the default process
     group. Returns (f32 [N,h,w], target_fps) on rank 0 — and on every rank when `all_ranks` (one broadcast of
     the stitched clip) — else (None, target_fps).
@@ -237,7 +300,21 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
     the ranks EXCHANGE the encoder taps their head jobs read (`exchange_taps`: one variable-split all-to-all per
     plane), then the HEADS run per the schedule: whole windows, and the last partial round's windows frame-sharded
     over groups of ranks. Otherwise `forward(window [1,32,3,H,W]) -> [1,32,H,W]` / `forward_sharded(local frames
-    [1,32/g,3,H,W], group) -> [1,32/g,H,W]` are called per job (tests inject stubs)."""
+    [1,32/g,3,H,W], group) -> [1,32/g,H,W]` are called per job (tests inject stubs).
+
+    The encoder runs in chunks of VDN_ENC_CHUNK (8) frames and the taps of chunk c travel while chunk c + 1 is encoded
+    (`TapExchange`). `stats` (a dict, optional): filled with this rank's seconds per phase — preprocess, encode,
+    tap_exchange_wait, heads, gather, stitch — and bytes it sent (taps, temporal all-to-alls, gather); the device is then
+    synchronised at every phase boundary, so pass it for a DIAGNOSTIC run, not for the timed one."""
+    import os
+    import time
+
+    def mark(name, t0):
+        if stats is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            stats[name] = stats.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
     assert group is None, "the schedule builds its own subgroups of the default group"
     P, r = world(), rank()
     fh, fw = frames[0].shape[:2]
@@ -267,12 +344,31 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
 
     pieces: List[torch.Tensor] = []   # this rank's depth frames in job order
     staged = forward is None and forward_sharded is None and hasattr(model, "encode_frames")
+    a2a0 = COUNTERS["a2a_bytes_sent"]
+    t0 = time.perf_counter()
     if staged:
         _, _, local, _, send = tap_exchange_plan(table, jobs, P, T)
         mine = local[r]
         x_mine = net_input(mine) if mine else net_input(table[0][:1])[:0]  # a rank may own no frame (tiny clips)
-        planes, rpf, hw = model.encode_frames(x_mine)   # rows per frame, (H, W) of the network input
-        got, where = exchange_taps(planes, rpf, mine, send, r)
+        t0 = mark("preprocess", t0)
+        chunk = max(1, int(os.environ.get("VDN_ENC_CHUNK", "8")))
+        if hasattr(model, "tap_planes"):       # the product: encode chunk by chunk, each chunk's taps leave while the next is encoded
+            planes, rpf, hw = model.tap_planes(x_mine)
+            ex = TapExchange(planes, rpf, mine, send, r, chunk)
+            for c in range(ex.nchunks):
+                c0, c1 = c * chunk, min(len(mine), (c + 1) * chunk)
+                if c1 > c0:
+                    model.encode_into(x_mine[c0:c1], planes, c0)
+                ex.send_chunk(c)
+        else:                                  # stand-in models: one pass, one exchange
+            planes, rpf, hw = model.encode_frames(x_mine)   # rows per frame, (H, W) of the network input
+            ex = TapExchange(planes, rpf, mine, send, r, max(1, max(len(l) for l in local)))
+            ex.send_chunk(0)
+        t0 = mark("encode", t0)
+        got, where = ex.finish()
+        t0 = mark("tap_exchange_wait", t0)
+        if stats is not None:
+            stats["bytes_taps_sent"] = ex.bytes_sent
         for (w, r0, g) in jobs:
             if not (r0 <= r < r0 + g):
                 continue
@@ -291,6 +387,7 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
                 k = r - r0
                 d = fwd_sh(net_input(table[w][k * Tl:(k + 1) * Tl])[None], groups[g][r0 // g])[0]
             pieces.append((resize(d, fh, fw) if resize else d).float())
+    t0 = mark("heads", t0)
 
     # ---- gather every rank's frames to rank 0 (equal slabs; the schedule tells who holds what)
     counts = [0] * P
@@ -306,6 +403,10 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
         gather_to(slab, parts, dst=0)
     else:
         parts = [slab]
+    t0 = mark("gather", t0)
+    if stats is not None:
+        stats["bytes_gather_sent"] = 0 if r == 0 else slab.numel() * 4
+        stats["bytes_temporal_a2a_sent"] = COUNTERS["a2a_bytes_sent"] - a2a0 - (stats.get("bytes_taps_sent", 0) if staged else 0)
     out = None
     if r == 0:
         allw = torch.empty((len(table), T, fh, fw), dtype=torch.float32, device=dev)
@@ -325,12 +426,15 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
         else:
             dn = allw.cpu().numpy()
             out = torch.from_numpy(util.stitch([dn[w, i] for w in range(len(table)) for i in range(T)], n)).to(dev)
+    t0 = mark("stitch", t0)
     if all_ranks and P > 1:
         if r != 0:
             out = torch.empty((n, fh, fw), dtype=torch.float32, device=dev)
         out = out.contiguous()
         broadcast_from(out, src=0)
-    return (None if out is None else util.to_host(out.contiguous())), target_fps
+    res = None if out is None else util.to_host(out.contiguous())
+    mark("to_host", t0)
+    return res, target_fps
 
 
 # --------------------------------------------------------------------------------------------- frames

@@ -136,6 +136,32 @@ class VideoDepthAnything(_EngineOwner):
                 planes.append(t.lo[:k * P])
         return planes, P, (H, W)
 
+    def tap_planes(self, x: torch.Tensor):
+        """Destination of `encode_into` for the k frames x [k,3,H,W]: (planes, rows_per_frame, (H, W)), the planes as
+        encode_frames returns them but not yet written."""
+        rt = self._engines()["rt"]
+        k, _, H, W = x.shape
+        P, C = (H // 14) * (W // 14), self.pretrained.embed_dim
+        out = [rt.hbuf(f"enc_share_tap{j}", (max(k, 1) * P, C)) for j in range(4)]
+        self._tap_out = out
+        planes = []
+        for t in out:
+            planes.append(t.hi[:k * P])
+            if t.lo is not None:
+                planes.append(t.lo[:k * P])
+        return planes, P, (H, W)
+
+    @torch.no_grad()
+    def encode_into(self, x: torch.Tensor, planes, first: int):
+        """Encode frames x [c,3,H,W] into rows [first * P, (first + c) * P) of the planes `tap_planes` handed out (the
+        multi-GPU driver encodes in chunks so that a chunk's taps travel while the next one is encoded)."""
+        e = self._engines()
+        rt, enc = e["rt"], e["enc"]
+        c, _, H, W = x.shape
+        P = (H // 14) * (W // 14)
+        xf = x.to(device=rt.device, dtype=torch.float32).contiguous()
+        enc.run(xf, tap_out=[t.narrow0(first * P, c * P) for t in self._tap_out])
+
     @torch.no_grad()
     def head_from_planes(self, planes, Tl: int, T: int, hw, group=None) -> torch.Tensor:
         """The temporal DPT head on the taps of Tl frames (planes as returned by encode_frames, rows of these Tl frames in
