@@ -398,7 +398,7 @@ def main():
     }
     if not a.stub:
         from vdn import _abi
-        out["config"]["attention_pv_products"] = int(_abi.lib.vdn_flash_attn_get_pv_products())
+        out["config"]["attention_pv_products"] = int(model._engines()["rt"].pv_products)
     if strong:
         jobs = plan_schedule(n_windows, n_gpus)
         out["config"]["schedule"] = {"windows": n_windows, "whole_window_jobs": sum(1 for j in jobs if j[2] == 1),

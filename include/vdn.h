@@ -40,6 +40,25 @@ enum vdn_store {
   VDN_ST_GEGLU = 3    /* weight rows packed as 16-row blocks [h | gate]; out = h * gelu(gate), or h * silu(gate) with act = VDN_ACT_SILU */
 };
 
+/* Kernel-selection knobs of vdn_gemm (which tile / pipeline / split-K variant a shape gets; never what is computed beyond
+ * fp32 summation order). The library holds NO mutable selection state: the defaults are read from the environment variables
+ * named below once, at the first use (vdn_gemm_get_tuning returns them), and a launch that wants other values points its
+ * descriptor's `tuning` at a struct of its own (tests pin a tile with force_bm; tools run A/B experiments). Thread-safe.   */
+typedef struct vdn_gemm_tuning {
+  int force_bm;     /* VDN_GEMM_BM       0 = cost model; 128 | 192 | 256 force the 8-wave kernels' M tile                  */
+  int p8;           /* VDN_GEMM_P8       1 = ping-pong 3-product kernel at BM 256 (default), 2 = also BM 192, 0 = never   */
+  int no_splitk;    /* VDN_GEMM_NOSPLITK 1 = never split K                                                                */
+  int no_pipe;      /* VDN_GEMM_NOPIPE   1 = lock-step loop without the phase shift                                       */
+  int splitk_p8;    /* VDN_SPLITK_P8     >= 2: K slices for deep residual linears on the ping-pong kernel                 */
+  int cus;          /* VDN_GEMM_CUS      > 0 overrides the CU count tiles are sized for (else desc.cu_hint / 256)          */
+  int splitk_occ;   /* VDN_SPLITK_OCC    split K when the 128-row tile grid covers <= this percent of the CUs (50)         */
+  int splitk_max;   /* VDN_SPLITK_MAX    most K slices (8)                                                                */
+  int min_tiles;    /* VDN_GEMM_MIN_TILES plain-A problems with fewer 128x256 tiles use the 4-wave 128x128 kernel (96)     */
+  float f128, f192; /* VDN_GEMM_F128/F192 cost factors of the smaller M tiles of the 3-product kernels (1.3, 1.2)          */
+  int x8;           /* VDN_GEMM_X8       1 (default): launches that carry A8 / W8 planes run on the 8-bit cross-term kernel; 0: rejected */
+} vdn_gemm_tuning;
+int vdn_gemm_get_tuning(vdn_gemm_tuning* out);   /* the environment-derived defaults */
+
 /* One descriptor drives every GEMM-shaped op on the path:
  *   out = epilogue( A[M,K] x W[N,K]^T ),  half operands, fp32 accumulate on MFMA.
  * Replaces F.linear / nn.Conv2d(1x1, 3x3 s1|s2 p1) / nn.ConvTranspose2d(k==s) at:
@@ -152,30 +171,10 @@ typedef struct vdn_gemm_desc {
    *           i.e. as the a_kt operand of the next GEMM (bias + GELU / plain half-plane flavours of the 8-bit kernel only).
    * vdn_layernorm and vdn_flash_attn produce the same layout (their `kt` arguments).                                      */
   int32_t a_kt, w_kt, out_kt;
+  const vdn_gemm_tuning* tuning;   /* NULL = the library defaults (vdn_gemm_get_tuning); else this launch's own knobs */
 } vdn_gemm_desc;
 
 int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
-
-/* Process-wide kernel-selection knobs of vdn_gemm (which tile / pipeline / split-K variant a shape gets; never
- * what is computed). Initialised ONCE, at the first use, from the environment variables named below; afterwards
- * only vdn_gemm_set_tuning changes them (tests pin a tile with force_bm; tools run A/B experiments). Not
- * thread-safe against concurrent launches: set before launching.                                             */
-typedef struct vdn_gemm_tuning {
-  int force_bm;     /* VDN_GEMM_BM       0 = pick_bm(); 128 | 192 | 256 force the 8-wave kernel's M tile          */
-  int p8;           /* VDN_GEMM_P8       1 = ping-pong kernel at BM 256 (default), 2 = also BM 192, 0 = never     */
-  int no_splitk;    /* VDN_GEMM_NOSPLITK 1 = never split K                                                        */
-  int no_pipe;      /* VDN_GEMM_NOPIPE   1 = lock-step loop without the phase shift                               */
-  int persist;      /* VDN_GEMM_PERSIST  1 = ping-pong kernel as 256 persistent workgroups (measured slower)      */
-  int splitk_p8;    /* VDN_SPLITK_P8     >= 2: K slices for deep residual linears on the ping-pong kernel         */
-  int cus;          /* VDN_GEMM_CUS      > 0 overrides the CU count tiles are sized for (else desc.cu_hint / 256)  */
-  int splitk_occ;   /* VDN_SPLITK_OCC    split K when the 128-row tile grid covers <= this percent of the CUs (50) */
-  int splitk_max;   /* VDN_SPLITK_MAX    most K slices (8)                                                        */
-  int min_tiles;    /* VDN_GEMM_MIN_TILES plain-A problems with fewer 128x256 tiles use the 4-wave 128x128 kernel (96) */
-  float f128, f192; /* VDN_GEMM_F128/F192 cost factors of the smaller M tiles in pick_bm (1.3, 1.2)               */
-  int x8;           /* VDN_GEMM_X8       1 (default): launches that carry A8 / W8 planes use the 8-bit cross-term kernel (an experiment: slower than the 3-product kernel) */
-} vdn_gemm_tuning;
-int vdn_gemm_get_tuning(vdn_gemm_tuning* out);
-int vdn_gemm_set_tuning(const vdn_gemm_tuning* in);
 
 /* LayerNorm over the last dim of [rows, C] (fp32 statistics, two-pass in registers).
  *   y = LN(x) * w + b;  y += alpha * addvec[c];  y += addtab[(row / tab_div) % tab_mod, c]
@@ -205,23 +204,16 @@ int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, cons
  *   with rows = B nq (vdn_gemm_desc.a_kt).                                                                                 */
 int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                    const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, void* out8, int out_kt,
-                   int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream);
-/* Split-plane mode only: MFMA products per P V term. 2: the softmax weights, born in registers, are
- * rounded once to 16 bits and the row sum uses the same rounded weights (O = sum p~ V / sum p~, V at 21 bits): each
- * weight is off by <= 2^-11 relative, common factors cancel. 3: P is split into hi / lo planes too (every output
- * within ~1e-6 of fp64 at ~13 % more kernel time). 1 (the DEFAULT; fp16 planes with Q8 / K8 only, else treated as 2): V
- * enters as its hi plane alone, which the producer rounds to nearest (vdn_gemm writes the hi plane of TRANSPOSED head splits that way; lo = remainder): every output
- * element is a convex combination of fp16-rounded V values, i.e. within 2^-12 relative of the 2-product result at worst;
- * 2e-5..9e-5 end to end on the fixtures against the 1e-3 tolerance (2: 7e-6..2e-5), 14-17 % less kernel time.
- * Process-wide; set it before the first forward (a memory bank keeps the V planes its producer wrote).
- * VDN_ATTN_PV = 1 | 2 | 3 sets the default. */
-int vdn_flash_attn_set_pv_products(int n);
-int vdn_flash_attn_get_pv_products(void);
-/* Instruction stream of the attention with 8-bit cross terms (same products, same arithmetic per element): 2 (default) =
- * generated stream with S and P double-buffered by tile parity and the softmax as a 3-stage pipeline across MFMA gaps;
- * 1 = the hand-placed 48-slot stream of round 1 (A/B and regression). Process-wide. VDN_ATTN_STREAM=1 = default 1. */
-int vdn_flash_attn_set_stream(int v);
-int vdn_flash_attn_get_stream(void);
+                   int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, int pv_products, vdn_stream stream);
+/* pv_products (split-plane mode only; 0 = the default, 1): MFMA products per P V term — a PER-CALL argument, the library keeps
+ * no selection state. 2: the softmax weights, born in registers, are rounded once to 16 bits and the row sum uses the same
+ * rounded weights (O = sum p~ V / sum p~, V at 21 bits): each weight is off by <= 2^-11 relative, common factors cancel.
+ * 3: P is split into hi / lo planes too (every output within ~1e-6 of fp64 at ~13 % more kernel time; reads the fp16 lo
+ * planes of Q and K, so their producer must write them). 1 (fp16 planes with Q8 / K8 only, else treated as 2): V enters as
+ * its hi plane alone, which the producer rounds to nearest (vdn_gemm writes the hi plane of TRANSPOSED head splits that
+ * way; lo = remainder): every output element is a convex combination of fp16-rounded V values, i.e. within 2^-12 relative of
+ * the 2-product result at worst; 2e-5..9e-5 end to end on the fixtures against the 1e-3 tolerance (2: 7e-6..2e-5), 14-17 %
+ * less kernel time. A memory bank keeps the V planes its producer wrote: use one value per model. */
 
 /* Temporal attention over <=64 frames per (pixel, head) (32 in the 32-frame windows, 64 in the v5 refiner): qkv half [(b f), D, 3c] packed
  * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)
@@ -256,6 +248,13 @@ int vdn_fill_row(float* x, const float* vec, int B, int rows_per_b, int row, int
  * kernel cv2.INTER_CUBIC applies to frames (util/transform.py:113).                               */
 int vdn_bicubic(const float* src, float* dst, int ih, int iw, int oh, int ow, int C, float scale_rows,
                 float scale_cols, vdn_stream stream);
+
+/* The whole pre-processing of a batch of frames in ONE launch (depth_anything_v2.py:67-92, util/transform.py:109-157,
+ * video_depth.py:73-99): u8 [n, h, w, 3] HOST-ORDER RGB (swap_rb = 0) or BGR (swap_rb = 1: cv2.cvtColor(BGR2RGB)) -> /255 ->
+ * cubic resize to (H, W) with the taps of vdn_bicubic (identity when (H, W) == (h, w)) -> (v - mean[c]) / std[c] ->
+ * f32 [n, 3, H, W]. mean3 / std3: 3 HOST floats each (ImageNet: .485 .456 .406 / .229 .224 .225).                    */
+int vdn_preprocess(const uint8_t* frames, int n, int h, int w, int swap_rb, float* out, int H, int W, const float* mean3,
+                   const float* std3, vdn_stream stream);
 
 /* y = x + alpha * vec[c]  (memory_attention.py:141)                                               */
 int vdn_add_vec(const float* x, const float* vec, float alpha, float* y, int rows, int C, vdn_stream stream);

@@ -20,10 +20,10 @@ def golden_dir():
 
 @pytest.fixture
 def tune():
-    """Pin vdn_gemm's kernel selection for one test through the C-ABI (vdn_gemm_set_tuning) and restore it after:
+    """Pin vdn_gemm's kernel selection for one test (the knobs travel per launch in vdn_gemm_desc.tuning) and restore it after:
     `tune(force_bm=192)`. The library reads its VDN_GEMM_* environment defaults once per process, never per launch."""
     from vdn import _abi
-    saved = _abi.get_tuning()
+    saved = _abi.OVERRIDE
 
     def _set(**kw):
         _abi.set_tuning(**kw)

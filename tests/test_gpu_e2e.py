@@ -418,26 +418,23 @@ def test_single_pass_modes_error_is_reported_and_bounded(precision, limit):
 @pytest.mark.parametrize("pv,limit", [(1, 2e-4), (2, 4e-5), (3, 3e-5)])   # 3: fp16 lo planes of Q / K must be written (runtime.qk_dst)
 @pytest.mark.parametrize("name,enc", [("A_vitl_518", "vitl"), ("A_vits_518", "vits")])
 def test_pv_product_modes_error_is_reported_and_bounded(name, enc, pv, limit):
-    """vdn_flash_attn_set_pv_products: 1 (the default) = V enters the attention as ONE fp16 plane rounded to nearest (P~ V_hi:
-    20 instead of 28 MFMAs per 64-key tile), 2 = P~ (V_hi + V_lo), fp32-faithful. The whole 8-frame stream — memory depth
-    0..6 and the eviction — against the reference fixture: measured 2e-5..9e-5 (1) and 7e-6..2e-5 (2) against the 1e-3 bar."""
-    from vdn import _abi
+    """pv_products of vdn_flash_attn (per call; model.set_attention_pv): 1 (the default) = V enters the attention as ONE fp16
+    plane rounded to nearest (P~ V_hi: 20 instead of 28 MFMAs per 64-key tile), 2 = P~ (V_hi + V_lo), 3 = P split into planes
+    too (reads the fp16 lo planes of Q / K, which the projections then write). The whole 8-frame stream — memory depth 0..6
+    and the eviction — against the reference fixture: measured 2e-5..9e-5 (1) and 7e-6..2e-5 (2) against the 1e-3 bar."""
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     _, steps, H, W, sub, _ = [int(v) for v in g["meta"]]
     kept = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("pre_") and not k.startswith("pre_stats"))
-    default = _abi.lib.vdn_flash_attn_get_pv_products()
-    assert _abi.lib.vdn_flash_attn_set_pv_products(pv) == 0
-    try:
-        model = _product("A", enc)
-        x = inputs(steps, H, W).reshape(steps, 1, 3, H, W)
-        for t in range(max(kept) + 1):
-            pre = model.forward(x[t].cuda(), _pre_relu=True).cpu()
-            if t in kept:
-                e = rel_l2(torch.relu(pre[:, ::sub, ::sub]), np.maximum(g[f"pre_{t}"], 0))
-                print(f"[{name} pv={pv}] frame {t}: vs reference fixture post-ReLU {e:.2e}")
-                assert e < limit, (t, e)
-    finally:
-        _abi.lib.vdn_flash_attn_set_pv_products(default)
+    model = _product("A", enc)
+    model.set_attention_pv(pv)
+    assert model._engines()["rt"].pv_products == pv
+    x = inputs(steps, H, W).reshape(steps, 1, 3, H, W)
+    for t in range(max(kept) + 1):
+        pre = model.forward(x[t].cuda(), _pre_relu=True).cpu()
+        if t in kept:
+            e = rel_l2(torch.relu(pre[:, ::sub, ::sub]), np.maximum(g[f"pre_{t}"], 0))
+            print(f"[{name} pv={pv}] frame {t}: vs reference fixture post-ReLU {e:.2e}")
+            assert e < limit, (t, e)
 
 
 def test_frame_sharded_forward_matches_plain_on_one_rank():

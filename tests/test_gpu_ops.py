@@ -32,7 +32,7 @@ def h(t):  # half-rounded copy kept in f32 (what the kernel actually sees)
     return t.half().float()
 
 
-PV_DEFAULT = 1   # library default of vdn_flash_attn_set_pv_products (include/vdn.h); tests that change it put it back
+PV_DEFAULT = 1   # default pv_products of vdn_flash_attn (include/vdn.h); tests that change Runtime.pv_products put it back
 
 
 def close(got, ref, tol):
@@ -488,17 +488,17 @@ def test_x3_heads_rope_and_flash(rt3):
     close(vd.float().reshape(B, Hh, 64, tp)[:, :, :, :P], v.transpose(2, 3), 5e-6)
     out = rt3.hbuf("t_o", (B * P, C))
     for pv, tol in ((3, 1e-5), (2, 3e-4)):  # P split into planes / P rounded once to 16 bits (include/vdn.h)
-        _abi.lib.vdn_flash_attn_set_pv_products(pv)
+        rt3.pv_products = pv
         try:
             rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125)
         finally:
-            _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
+            rt3.pv_products = PV_DEFAULT
         close(out.float().reshape(B, P, C), ref, tol)
-    _abi.lib.vdn_flash_attn_set_pv_products(2)
+    rt3.pv_products = 2
     try:
         rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125, q8=q8, k8=k8)  # score cross terms on the 8-bit MFMA
     finally:
-        _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
+        rt3.pv_products = PV_DEFAULT
     close(out.float().reshape(B, P, C), ref, 3e-4)
     # one-product P V: the projection rounds V^T's hi plane to NEAREST (lo = remainder); the kernel reads hi alone
     vt_ref = v.transpose(2, 3).reshape(B * Hh, 64, P).to(DEV)
@@ -508,19 +508,18 @@ def test_x3_heads_rope_and_flash(rt3):
     assert ((got_hi.float() - vt_ref).abs() <= vt_ref.abs() * 2.0 ** -11 * 1.01 + 1e-6).all()
     assert (got_hi == vt_ref.half()).float().mean() > 0.99
     close(vd.float().reshape(B, Hh, 64, tp)[:, :, :, :P], v.transpose(2, 3), 5e-6)
-    _abi.lib.vdn_flash_attn_set_pv_products(1)
+    rt3.pv_products = 1
     try:
         rt3.flash_attn(qd, kd, vd, out, B, Hh, P, tp, P, tp, 0.125, q8=q8, k8=k8)
     finally:
-        _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
+        rt3.pv_products = PV_DEFAULT
     close(out.float().reshape(B, P, C), ref, 4e-4)
 
 
-@pytest.mark.parametrize("pv,tol,qk8,stream", [(3, 1e-5, False, 2), (2, 3e-4, False, 2), (2, 3e-4, True, 2), (2, 3e-4, True, 1),
-                                               (1, 4e-4, True, 2)])
+@pytest.mark.parametrize("pv,tol,qk8", [(3, 1e-5, False), (2, 3e-4, False), (2, 3e-4, True), (1, 4e-4, True)])
 @pytest.mark.parametrize("nq,nk,gain", [(150, 200, 1.0), (1370, 1370, 1.0), (37, 64, 1.0), (70, 128, 1.0), (100, 130, 1.0),
                                         (129, 777, 6.0), (40, 8214, 1.0), (300, 321, 3.0)])
-def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
+def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8):
     """1 / 2 / 3 / many key tiles (the software pipeline's prologue, peeled first and last iterations), ragged
     last tile; gain 6 makes row maxima jump by far more than the lazy-rescale threshold between tiles.
     pv = 3: P carried as hi/lo planes, fp32-faithful (1e-5 against fp64). pv = 2 (the default): every softmax weight
@@ -529,13 +528,12 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
     rounding, 2^-12 per element, to that); end to end it is invisible
     (tests/test_gpu_e2e.py prints 4e-6..1e-5 either way). qk8: the score cross terms K_hi Q_lo^T + K_lo Q_hi^T on the
     block-scaled e5m2 MFMA from the 8-bit planes (built here as the projection epilogue builds them); its own error
-    (~1e-5 of a logit) disappears under the pv = 2 rounding. stream: with the 8-bit planes, 2 = flash_attn2_kernel (the default:
-    generated instruction stream, S and P double-buffered by tile parity — 1, 2, 3, 4, 6, 13, 22 and 129 tiles walk every
-    first / even / odd / last instantiation), 1 = the hand-placed 48-slot kernel; same products, so both meet the same bound."""
+    (~1e-5 of a logit) disappears under the pv = 2 rounding. With the 8-bit planes the kernel is flash_attn2_kernel (generated
+    instruction stream, S and P double-buffered by tile parity — 1, 2, 3, 4, 6, 13, 22 and 129 tiles walk every
+    first / even / odd / last instantiation). pv is the per-call pv_products argument of vdn_flash_attn (Runtime.pv_products)."""
     from vdn import _abi
     from vdn.runtime import ceil_to
-    _abi.lib.vdn_flash_attn_set_pv_products(pv)
-    assert _abi.lib.vdn_flash_attn_set_stream(stream) == 0 and _abi.lib.vdn_flash_attn_get_stream() == stream
+    rt3.pv_products = pv
     B, H = 1, 2
     q, k, v = rnd(B, H, nq, 64, seed=230, scale=gain), rnd(B, H, nk, 64, seed=231), rnd(B, H, nk, 64, seed=232)
     ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(1, 2).reshape(B, nq, H * 64)
@@ -567,8 +565,7 @@ def test_x3_flash_attention(rt3, nq, nk, gain, pv, tol, qk8, stream):
             rt3.flash_attn(qd, kd, vd, out, B, H, nq, qp, nk, kp, 0.125, q8=q8, k8=k8)
             assert torch.equal(out.hi, first[0]) and torch.equal(out.lo, first[1])
     finally:
-        _abi.lib.vdn_flash_attn_set_pv_products(PV_DEFAULT)
-        _abi.lib.vdn_flash_attn_set_stream(2)
+        rt3.pv_products = PV_DEFAULT
 
 
 @pytest.mark.parametrize("T", [32, 64, 50])

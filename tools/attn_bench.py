@@ -7,7 +7,6 @@ import torch
 from vdn.runtime import Runtime, ceil_to
 split = "--single" not in sys.argv
 from vdn import _abi
-print("attention stream", _abi.lib.vdn_flash_attn_get_stream(), "(VDN_ATTN_STREAM)", flush=True)
 rt = Runtime(torch.device("cuda:0"), torch.float16, split=split)
 B, H = 8, 16
 for name, nq, nk in (("encoder", 1370, 1370), ("mem_self", 1369, 1369), ("mem_cross_S6", 1369, 6 * 1369)):

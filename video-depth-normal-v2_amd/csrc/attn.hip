@@ -668,36 +668,19 @@ __global__ __launch_bounds__(256) void temporal_last_kernel(const float* __restr
   for (int e = 0; e < CPL; ++e) store_half(out, out_lo, (size_t)px * c + ch + e, o[e]);
 }
 
-// process-wide: MFMA products per P V term in split mode: 1 (default), 2 or 3 (include/vdn.h). VDN_ATTN_PV = 1 | 2 | 3
-// (or the older VDN_ATTN_PV3=1) sets the default at the first use.
-int& pv_products() {
-  static int v = [] {
-    const char* e = getenv("VDN_ATTN_PV");
-    if (e && atoi(e) >= 1 && atoi(e) <= 3) return atoi(e);
-    e = getenv("VDN_ATTN_PV3");
-    return (e && atoi(e) != 0) ? 3 : 1;
-  }();
-  return v;
-}
-
-// process-wide: instruction stream of the default-mode attention: 2 = flash_attn2_kernel (generated stream, S and P double
-// buffered), 1 = flash_attn_kernel<QK8> (hand-placed 48-slot stream). VDN_ATTN_STREAM=1 selects the older one at the first use.
-int& attn_stream() {
-  static int v = [] { const char* e = getenv("VDN_ATTN_STREAM"); return (e && atoi(e) == 1) ? 1 : 2; }();
-  return v;
-}
-
+// pv: MFMA products per P V term in split mode (include/vdn.h): 1 (default), 2 or 3 — a per-call argument: the library keeps
+// no selection state.
 template <int DT>
 int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const void* Ql, const void* Kl, const void* Vtl,
                  void* outl, const void* Q8, const void* K8, void* out8, int out_kt, int B, int H, int nq, int nq_pad, int nk, int nk_pad,
-                 float sl2, hipStream_t s) {
+                 float sl2, int pv, hipStream_t s) {
   using T = typename Half<DT>::T;
   const dim3 grid(((nq + 127) / 128) * B * H);
-  const bool pv3 = pv_products() == 3;  // the 3-product P V with P split into hi / lo planes (vdn_flash_attn_set_pv_products)
+  const bool pv3 = pv == 3;  // the 3-product P V with P split into hi / lo planes
   const uint8_t* q8 = (const uint8_t*)Q8;
   const uint8_t* k8 = (const uint8_t*)K8;
   // the 8-bit / K-tile-major output planes and a lo-less output exist in the default kernel only (fp16 split planes + Q8 / K8)
-  if ((out8 || out_kt || (Ql && !outl)) && !(Ql && !pv3 && q8 && k8 && DT == VDN_F16 && attn_stream() == 2)) return VDN_EUNSUPPORTED;
+  if ((out8 || out_kt || (Ql && !outl)) && !(Ql && !pv3 && q8 && k8 && DT == VDN_F16)) return VDN_EUNSUPPORTED;
   if (Ql && pv3)
     hipLaunchKernelGGL((flash_attn_kernel<DT, true, false, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
                        (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
@@ -708,15 +691,12 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
 #endif
       constexpr int NW = VDN_ATTN2_NW;
       const dim3 grid2(((nq + 32 * NW - 1) / (32 * NW)) * B * H);
-      if (attn_stream() == 2 && pv_products() == 1)
+      if (pv == 1)
         hipLaunchKernelGGL((flash_attn2_kernel<1, NW>), grid2, dim3(64 * NW), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
                            (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2, (uint8_t*)out8, out_kt, B * nq);
-      else if (attn_stream() == 2)
+      else
         hipLaunchKernelGGL((flash_attn2_kernel<2, NW>), grid2, dim3(64 * NW), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt, (T*)out,
                            (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2, (uint8_t*)out8, out_kt, B * nq);
-      else
-      hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, true>), grid, dim3(256), (VDN_ATTN_ABL & 32) ? 98304 : 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
-                         (T*)out, (const T*)Ql, (const T*)Kl, (const T*)Vtl, (T*)outl, q8, k8, H, nq, nq_pad, nk, nk_pad, sl2);
     }
   } else if (Ql)
     hipLaunchKernelGGL((flash_attn_kernel<DT, true, true, false>), grid, dim3(256), 65536, s, (const T*)Q, (const T*)K, (const T*)Vt,
@@ -749,23 +729,13 @@ int temporal_launch(const void* qkv, void* out, const void* qkv_lo, void* out_lo
 
 }  // namespace
 
-extern "C" int vdn_flash_attn_set_pv_products(int n) {
-  if (n < 1 || n > 3) return VDN_EINVAL;
-  pv_products() = n;
-  return VDN_OK;
-}
-extern "C" int vdn_flash_attn_get_pv_products(void) { return pv_products(); }
-extern "C" int vdn_flash_attn_set_stream(int v) {
-  if (v != 1 && v != 2) return VDN_EINVAL;
-  attn_stream() = v;
-  return VDN_OK;
-}
-extern "C" int vdn_flash_attn_get_stream(void) { return attn_stream(); }
-
 extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                               const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, void* out8,
-                              int out_kt, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, vdn_stream stream) {
+                              int out_kt, int B, int H, int nq, int nq_pad, int nk, int nk_pad, float scale, int pv_products,
+                              vdn_stream stream) {
   if (!Q || !K || !Vt || !out || B <= 0 || H <= 0 || nq <= 0 || nk <= 0) return VDN_EINVAL;
+  if (pv_products < 0 || pv_products > 3) return VDN_EINVAL;
+  const int pv = pv_products ? pv_products : 1;
   if (nq_pad < nq || nk_pad < nk || (nk_pad & 63)) return VDN_EALIGN;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)out) & 15) return VDN_EALIGN;
   const int nlo = (Q_lo != nullptr) + (K_lo != nullptr) + (Vt_lo != nullptr);
@@ -776,9 +746,9 @@ extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* 
   const float sl2 = scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;
   if (dt == VDN_F16)
-    return flash_launch<VDN_F16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, Q8, K8, out8, out_kt, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
+    return flash_launch<VDN_F16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, Q8, K8, out8, out_kt, B, H, nq, nq_pad, nk, nk_pad, sl2, pv, s);
   if (dt == VDN_BF16)
-    return flash_launch<VDN_BF16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, nullptr, nullptr, out8, out_kt, B, H, nq, nq_pad, nk, nk_pad, sl2, s);
+    return flash_launch<VDN_BF16>(Q, K, Vt, out, Q_lo, K_lo, Vt_lo, out_lo, nullptr, nullptr, out8, out_kt, B, H, nq, nq_pad, nk, nk_pad, sl2, pv, s);
   return VDN_EUNSUPPORTED;
 }
 

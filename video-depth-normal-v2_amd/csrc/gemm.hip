@@ -15,14 +15,13 @@ static float env_float(const char* name, float dflt) {
   const char* e = getenv(name);
   return e ? (float)atof(e) : dflt;
 }
-static vdn_gemm_tuning& tuning_rw() {
-  static vdn_gemm_tuning t = [] {  // the environment is read here, once per process
+static const vdn_gemm_tuning& tuning_defaults() {
+  static const vdn_gemm_tuning t = [] {  // the environment is read here, once per process; immutable afterwards
     vdn_gemm_tuning v;
     v.force_bm = env_int("VDN_GEMM_BM", 0);
     v.p8 = env_int("VDN_GEMM_P8", 1);
     v.no_splitk = getenv("VDN_GEMM_NOSPLITK") != nullptr;
     v.no_pipe = getenv("VDN_GEMM_NOPIPE") != nullptr;
-    v.persist = env_int("VDN_GEMM_PERSIST", 0);
     v.splitk_p8 = env_int("VDN_SPLITK_P8", 0);
     v.cus = env_int("VDN_GEMM_CUS", 0);
     v.splitk_occ = env_int("VDN_SPLITK_OCC", 50);
@@ -35,19 +34,13 @@ static vdn_gemm_tuning& tuning_rw() {
   }();
   return t;
 }
-const vdn_gemm_tuning& tuning() { return tuning_rw(); }
+const vdn_gemm_tuning& tuning(const vdn_gemm_desc& d) { return d.tuning ? *d.tuning : tuning_defaults(); }
 }
 
 extern "C" int vdn_gemm_get_tuning(vdn_gemm_tuning* out) {
   if (!out) return VDN_EINVAL;
-  *out = vdn_gemm_impl::tuning_rw();
-  return VDN_OK;
-}
-extern "C" int vdn_gemm_set_tuning(const vdn_gemm_tuning* in) {
-  if (!in) return VDN_EINVAL;
-  if (in->force_bm != 0 && in->force_bm != 128 && in->force_bm != 192 && in->force_bm != 256) return VDN_EINVAL;
-  if (in->splitk_occ < 0 || in->splitk_max < 0 || in->min_tiles < 0 || in->cus < 0 || in->cus > 256) return VDN_EINVAL;
-  vdn_gemm_impl::tuning_rw() = *in;
+  vdn_gemm_desc none = {};
+  *out = vdn_gemm_impl::tuning(none);
   return VDN_OK;
 }
 
@@ -55,6 +48,12 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if (!dp) return VDN_EINVAL;
   const vdn_gemm_desc& d = *dp;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.W || !d.zeros) return VDN_EINVAL;
+  if (d.tuning) {
+    const vdn_gemm_tuning& t = *d.tuning;
+    if ((t.force_bm != 0 && t.force_bm != 128 && t.force_bm != 192 && t.force_bm != 256) || t.splitk_occ < 0 || t.splitk_max < 0 ||
+        t.min_tiles < 0 || t.cus < 0 || t.cus > 256)
+      return VDN_EINVAL;
+  }
   if (d.dt != VDN_F16 && d.dt != VDN_BF16) return VDN_EUNSUPPORTED;
   if ((d.K & 7) || (d.ldb & 63) || d.ldb < d.K) return VDN_EALIGN;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.W & 15) || ((uintptr_t)d.zeros & 15)) return VDN_EALIGN;

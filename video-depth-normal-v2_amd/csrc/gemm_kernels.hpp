@@ -20,9 +20,9 @@
 
 namespace vdn_gemm_impl {
 
-// Process-wide kernel-selection knobs (include/vdn.h: vdn_gemm_tuning). Read from VDN_GEMM_* / VDN_SPLITK_* ONCE, at
-// the first launch; tests and tools change them through vdn_gemm_set_tuning(), never through the environment per launch.
-const vdn_gemm_tuning& tuning();  // gemm.hip
+// Kernel-selection knobs of a launch (include/vdn.h: vdn_gemm_tuning): the descriptor's own, or the defaults read from
+// VDN_GEMM_* / VDN_SPLITK_* ONCE at the first use (immutable afterwards: no process-wide mutable state).
+const vdn_gemm_tuning& tuning(const vdn_gemm_desc& d);  // gemm.hip
 
 constexpr int BK = 64;
 
@@ -1502,7 +1502,7 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + 255) / 256);
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * 256 * 64);
   const dim3 g(tiles), b(512);
-  const bool no_pipe = tuning().no_pipe != 0;
+  const bool no_pipe = tuning(d).no_pipe != 0;
   constexpr bool CAN_PIPE = BM <= 192;  // BM = 256 has no registers for the second W fragment set
   const bool pipe = CAN_PIPE && !no_pipe;
 #define VDN_LAUNCH_BIG(AM, ST)                                                                          \
@@ -1529,8 +1529,8 @@ int launch_x3_big(const vdn_gemm_desc& d, hipStream_t s) {
     // measured (tools/gemm_bench.py): the ping-pong loop runs at 97 % of the clock-limited MFMA rate at BM 256
     // (24 MFMAs cover a load segment) but not at BM 192 (18 do not), where the lock-step PIPE loop is as fast:
     // default = BM 256 only; VDN_GEMM_P8=2 also BM 192, =0 never.
-    if (tuning().p8 >= (BM == 256 ? 1 : 2)) {
-      const dim3 g8 = (tuning().persist != 0 && tiles > 256) ? dim3(256) : g;  // experiment: 256 persistent workgroups
+    if (tuning(d).p8 >= (BM == 256 ? 1 : 2)) {
+      const dim3 g8 = g;
 #define VDN_LAUNCH_P8(AM, ST) hipLaunchKernelGGL((gemm_x3_p8_kernel<DT, AM, ST, BM>), g8, b, lds, s, d)
       if (d.a_mode == VDN_A_CONV3X3) {
 #define VDN_CONV_P8(ST) do { if (d.relu_a) VDN_LAUNCH_P8(2, ST); else VDN_LAUNCH_P8(1, ST); } while (0)
@@ -1630,15 +1630,15 @@ int launch_splitk(const vdn_gemm_desc& d0, int ksplit, int fl, hipStream_t s) {
 template <int DT> int splitk_entry(const vdn_gemm_desc& d, int ksplit, int fl, hipStream_t s);  // defined in gemm_big_*.hip
 
 // Pick the M tile that wastes the fewest CU-rounds: cost = rounds(256 CUs) * BM, padded work included.
-inline int pick_bm(int M, int N, int cu_hint) {
+inline int pick_bm(int M, int N, int cu_hint, const vdn_gemm_tuning& tu) {
   const int tn = (N + 255) / 256;
-  const int cus = tuning().cus > 0 ? tuning().cus : (cu_hint > 0 && cu_hint <= 256 ? cu_hint : 256);  // CUs one launch can count on
+  const int cus = tu.cus > 0 ? tu.cus : (cu_hint > 0 && cu_hint <= 256 ? cu_hint : 256);  // CUs one launch can count on
   int best = 0;
   double best_cost = 1e30;
   for (int bm : {256, 192, 128}) {
     const long tiles = (long)((M + bm - 1) / bm) * tn;
     const long rounds = (tiles + cus - 1) / cus;
-    const double cost = (double)rounds * bm * (bm == 128 ? tuning().f128 : (bm == 192 ? tuning().f192 : 1.0));  // smaller tiles feed worse
+    const double cost = (double)rounds * bm * (bm == 128 ? tu.f128 : (bm == 192 ? tu.f192 : 1.0));  // smaller tiles feed worse
     if (cost < best_cost) { best_cost = cost; best = bm; }
   }
   return best;
@@ -1649,7 +1649,7 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   // 8-bit cross terms (gemm_x8.hip): plain A, fp16, K a multiple of 64, enough rows to fill 256 x 256 tiles
   if constexpr (DT == VDN_F16) {
     if (d.A8 && d.W8) {
-      if (d.a_mode == VDN_A_PLAIN && !d.relu_a && !(d.K & 63) && d.N >= 192 && (long)d.M * d.N >= 1024L * 1024 && tuning().x8 != 0)
+      if (d.a_mode == VDN_A_PLAIN && !d.relu_a && !(d.K & 63) && d.N >= 192 && (long)d.M * d.N >= 1024L * 1024 && tuning(d).x8 != 0)
         return x8_entry(d, s);
       // only that kernel reads K-tile-major planes and writes out8 / a lo-less half output
       if (d.a_kt || d.w_kt || d.out_kt || d.out8 || !d.A_lo || !d.W_lo) return VDN_EUNSUPPORTED;
@@ -1659,7 +1659,7 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
   const bool deep = d.splitk_ws && (d.a_mode == VDN_A_CONV3X3 ? d.ldb : d.K) >= 2048 && (long)d.M * d.N >= 32L * 1024;
   if (d.A_lo && d.W_lo && d.N >= 192 && ((long)d.M * d.N >= 256L * 1024 || deep) &&
       (d.a_mode == VDN_A_CONV3X3 ? d.store == VDN_ST_PLAIN : ((d.K & 31) == 0 && !d.relu_a))) {
-    const vdn_gemm_tuning& tu = tuning();
+    const vdn_gemm_tuning& tu = tuning(d);
     const int force = tu.force_bm;
     if (d.splitk_ws && !force && !(d.N & 3) && !tu.no_splitk) {
       const bool conv = d.a_mode == VDN_A_CONV3X3;
@@ -1685,7 +1685,7 @@ int launch_dt(const vdn_gemm_desc& d, hipStream_t s) {
           (long)d.M * d.N * 4 * ks <= d.splitk_ws_bytes)
         return splitk_entry<DT>(d, -ks, VDN_STX_RES, s);
     }
-    const int bm = force ? force : pick_bm(d.M, d.N, d.cu_hint);
+    const int bm = force ? force : pick_bm(d.M, d.N, d.cu_hint, tu);
     // small problems (batch 1: M = 1370): a grid of 128 x 256 tiles covers a fraction of the chip; the 4-wave 128 x 128
     // kernel launches twice the workgroups (two per CU) with half the K-loop work each
     // (batch 1: 15.9 -> 14.8 ms per frame, batch 2: 18.4 -> 17.3 ms with the threshold at 96 tiles)

@@ -437,7 +437,7 @@ static int x8_launch(const vdn_gemm_desc& d, hipStream_t s) {
 // M tile: the one that needs the least tile-row-rounds of the CUs this launch can count on (192-row tiles run 8 % slower
 // per row: 12 instead of 16 MFMAs per phase between the same two barriers, and W is re-read per 192 instead of 256 rows)
 int x8_entry(const vdn_gemm_desc& d, hipStream_t s) {
-  const vdn_gemm_tuning& tu = tuning();
+  const vdn_gemm_tuning& tu = tuning(d);
   const int cus = tu.cus > 0 ? tu.cus : (d.cu_hint > 0 && d.cu_hint <= 256 ? d.cu_hint : 256);
   const long tn = (d.N + X8_BN - 1) / X8_BN;
   auto cost = [&](int bm, double f) { const long t = (long)((d.M + bm - 1) / bm) * tn; return (double)((t + cus - 1) / cus) * bm * f; };

@@ -170,6 +170,49 @@ __global__ void bicubic_kernel(const float* __restrict__ src, float* __restrict_
   }
 }
 
+// vdn_preprocess: the whole pre-processing of a batch of frames in one launch — u8 [n,h,w,3] (RGB, or BGR with swap_rb) ->
+// /255 -> cubic resize to (H, W) (same taps as bicubic_kernel: A = -0.75, half-pixel centres, border clamp; identity-sized
+// inputs hit the weights {0,1,0,0} exactly) -> (v - mean[c]) / std[c] -> f32 NCHW. One thread per output pixel, 3 channels.
+struct PrepNorm { float mean[3], inv_std[3]; };
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n, int ih, int iw,
+                                                         int oh, int ow, float inv_sy, float inv_sx, int swap_rb, PrepNorm nm) {
+  const size_t per = (size_t)oh * ow, total = per * n;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int f = (int)(i / per);
+    const size_t p = i - (size_t)f * per;
+    const int ox = (int)(p % ow), oy = (int)(p / ow);
+    const float fy = ((float)oy + 0.5f) * inv_sy - 0.5f;
+    const float fx = ((float)ox + 0.5f) * inv_sx - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - (float)iy, wy);
+    cubic_w(fx - (float)ix, wx);
+    const uint8_t* img = src + (size_t)f * ih * iw * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = iy - 1 + a;
+      yy = yy < 0 ? 0 : (yy > ih - 1 ? ih - 1 : yy);
+      float rowv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+        int xx = ix - 1 + bq;
+        xx = xx < 0 ? 0 : (xx > iw - 1 ? iw - 1 : xx);
+        const uint8_t* px = img + ((size_t)yy * iw + xx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rowv[c] += wx[bq] * ((float)px[c] / 255.0f);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wy[a] * rowv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int sc = swap_rb ? 2 - c : c;   // output channel c reads source channel sc
+      dst[((size_t)f * 3 + c) * per + p] = (acc[sc] - nm.mean[c]) * nm.inv_std[c];
+    }
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void head_out_kernel(const typename Half<DT>::T* __restrict__ feat,
                                                        const typename Half<DT>::T* __restrict__ feat_lo,
@@ -402,6 +445,21 @@ extern "C" int vdn_bicubic(const float* src, float* dst, int ih, int iw, int oh,
     return VDN_EINVAL;
   hipLaunchKernelGGL(bicubic_kernel, dim3(grid_for((size_t)oh * ow * C)), dim3(256), 0, (hipStream_t)stream, src, dst,
                      ih, iw, oh, ow, C, 1.0f / scale_rows, 1.0f / scale_cols);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
+
+extern "C" int vdn_preprocess(const uint8_t* frames, int n, int h, int w, int swap_rb, float* out, int H, int W, const float* mean3,
+                              const float* std3, vdn_stream stream) {
+  if (!frames || !out || !mean3 || !std3 || n <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return VDN_EINVAL;
+  PrepNorm nm;
+  for (int c = 0; c < 3; ++c) {
+    if (!(std3[c] > 0.f)) return VDN_EINVAL;
+    nm.mean[c] = mean3[c];
+    nm.inv_std[c] = 1.0f / std3[c];
+  }
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream, frames, out, n, h, w, H, W,
+                     (float)h / (float)H, (float)w / (float)W, swap_rb, nm);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }

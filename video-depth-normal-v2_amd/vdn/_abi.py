@@ -39,12 +39,13 @@ class GemmDesc(C.Structure):
         ("dst8", vp * 3),
         ("A8", vp), ("W8", vp), ("out8", vp),
         ("a_kt", i32), ("w_kt", i32), ("out_kt", i32),
+        ("tuning", vp),
     ]
 
 
 class GemmTuning(C.Structure):
-    """Mirror of vdn_gemm_tuning (include/vdn.h): process-wide kernel-selection knobs of vdn_gemm."""
-    _fields_ = [("force_bm", i32), ("p8", i32), ("no_splitk", i32), ("no_pipe", i32), ("persist", i32), ("splitk_p8", i32),
+    """Mirror of vdn_gemm_tuning (include/vdn.h): kernel-selection knobs of vdn_gemm, attached per launch (desc.tuning)."""
+    _fields_ = [("force_bm", i32), ("p8", i32), ("no_splitk", i32), ("no_pipe", i32), ("splitk_p8", i32),
                 ("cus", i32), ("splitk_occ", i32), ("splitk_max", i32), ("min_tiles", i32), ("f128", C.c_float),
                 ("f192", C.c_float), ("x8", i32)]
 
@@ -69,15 +70,10 @@ lib = _load()
 EXPORTS = {
     "vdn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "vdn_gemm_get_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
-    "vdn_gemm_set_tuning": (C.c_int, [C.POINTER(GemmTuning)]),
     "vdn_layernorm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp, C.c_float, fp, C.c_int, C.c_int,
                                 C.c_int, vp, vp, C.c_int, fp, vp, C.c_int, vp]),
     "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_int, C.c_int, C.c_float, vp]),
-    "vdn_flash_attn_set_pv_products": (C.c_int, [C.c_int]),
-    "vdn_flash_attn_get_pv_products": (C.c_int, []),
-    "vdn_flash_attn_set_stream": (C.c_int, [C.c_int]),
-    "vdn_flash_attn_get_stream": (C.c_int, []),
+                                 C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp,
                                 C.c_int, vp]),
@@ -86,6 +82,7 @@ EXPORTS = {
     "vdn_patchify": (C.c_int, [C.c_int, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_fill_row": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_bicubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+    "vdn_preprocess": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     "vdn_add_vec": (C.c_int, [fp, fp, C.c_float, fp, C.c_int, C.c_int, vp]),
     "vdn_head_out": (C.c_int, [C.c_int, vp, vp, fp, C.c_float, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vdn_depth_tail": (C.c_int, [C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, fp, fp, C.c_float, fp,
@@ -129,25 +126,40 @@ if (lib.vdn_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.vdn_offsetof_gemm_ze
     raise ImportError("vdn_gemm_desc layout mismatch between include/vdn.h and vdn/_abi.py — rebuild the library")
 
 
-def get_tuning() -> GemmTuning:
+# The library keeps no selection state: a launch carries its own knobs in desc.tuning. OVERRIDE is the Python host's
+# (process-wide, test / tool oriented) choice of what Runtime.gemm attaches to every descriptor; None = the library defaults.
+OVERRIDE = None
+
+
+def default_tuning() -> GemmTuning:
     t = GemmTuning()
     check(lib.vdn_gemm_get_tuning(C.byref(t)), "vdn_gemm_get_tuning")
     return t
 
 
-def set_tuning(**kw) -> GemmTuning:
-    """Change some vdn_gemm_tuning fields; returns the previous settings (restore with restore_tuning)."""
-    old, new = get_tuning(), get_tuning()
+def get_tuning() -> GemmTuning:
+    """The knobs Runtime.gemm launches with: the override if one is set, else the library's environment-derived defaults."""
+    t = GemmTuning()
+    C.memmove(C.byref(t), C.byref(OVERRIDE if OVERRIDE is not None else default_tuning()), C.sizeof(GemmTuning))
+    return t
+
+
+def set_tuning(**kw):
+    """Change some vdn_gemm_tuning fields for every later Runtime.gemm launch of this process; returns the previous state
+    (restore with restore_tuning)."""
+    global OVERRIDE
+    old, new = OVERRIDE, get_tuning()
     for k, v in kw.items():
         if not hasattr(new, k):
             raise AttributeError(k)
         setattr(new, k, v)
-    check(lib.vdn_gemm_set_tuning(C.byref(new)), "vdn_gemm_set_tuning")
+    OVERRIDE = new
     return old
 
 
-def restore_tuning(t: GemmTuning):
-    check(lib.vdn_gemm_set_tuning(C.byref(t)), "vdn_gemm_set_tuning")
+def restore_tuning(t):
+    global OVERRIDE
+    OVERRIDE = t
 
 
 def check(rc: int, what: str):

@@ -45,6 +45,14 @@ class _EngineOwner(nn.Module):
         self.precision, self._eng = name, None
         return self
 
+    def set_attention_pv(self, n: int):
+        """MFMA products per P V term of the attention (include/vdn.h vdn_flash_attn pv_products): 1 (default; $VDN_ATTN_PV),
+        2 or 3. A per-model setting handed to every attention launch; the engines are rebuilt (a memory bank keeps the V
+        planes its producer wrote)."""
+        assert n in (1, 2, 3), n
+        self.attention_pv, self._eng = n, None
+        return self
+
     def _apply(self, fn, *a, **k):
         self._eng = None
         return super()._apply(fn, *a, **k)
@@ -56,26 +64,20 @@ class _EngineOwner(nn.Module):
     def _runtime(self) -> Runtime:
         dev = next(self.parameters()).device
         _, (dtype, split) = _precision(self.precision)
-        return Runtime(dev, dtype, split)
+        rt = Runtime(dev, dtype, split)
+        if getattr(self, "attention_pv", None):
+            rt.pv_products = self.attention_pv
+        return rt
 
     @staticmethod
-    def preprocess(rt: Runtime, frames_rgb01: torch.Tensor, input_size: int) -> torch.Tensor:
-        """[n,h,w,3] f32 RGB in [0,1] on device -> f32 [n,3,H,W]: Resize(lower_bound, multiple of 14,
-        cubic) + NormalizeImage + PrepareForNet (util/transform.py:109-148). The cubic kernel is the
-        A=-0.75 half-pixel one cv2.INTER_CUBIC uses; cv2 itself is absent offline so this step is
-        parity-unpinned."""
-        n, h, w, _ = frames_rgb01.shape
+    def preprocess(rt: Runtime, frames_u8: torch.Tensor, input_size: int, swap_rb: bool = False) -> torch.Tensor:
+        """u8 [n,h,w,3] on the device (RGB, or BGR with swap_rb) -> f32 [n,3,H,W]: /255, Resize(lower_bound, multiple of 14,
+        cubic) + NormalizeImage + PrepareForNet (util/transform.py:109-148) in ONE launch (vdn_preprocess). The cubic kernel
+        is the A=-0.75 half-pixel one cv2.INTER_CUBIC uses; cv2 itself is absent offline so this step is parity-unpinned
+        (SURVEY.md §8c)."""
+        n, h, w, _ = frames_u8.shape
         nw, nh = util.get_size(w, h, input_size)
-        mean = torch.tensor(_MEAN, device=rt.device)
-        std = torch.tensor(_STD, device=rt.device)
-        if (nh, nw) == (h, w):
-            res = frames_rgb01
-        else:
-            res = torch.empty((n, nh, nw, 3), dtype=torch.float32, device=rt.device)
-            src = frames_rgb01.contiguous()
-            for i in range(n):
-                rt.bicubic(src[i], res[i], h, w, nh, nw, 3, nh / h, nw / w)
-        return ((res - mean) / std).permute(0, 3, 1, 2).contiguous()
+        return rt.preprocess_u8(frames_u8.contiguous(), nh, nw, _MEAN, _STD, swap_rb)
 
 
 class DepthAnythingV2(_EngineOwner):
@@ -116,6 +118,7 @@ class DepthAnythingV2(_EngineOwner):
             lanes = []
             for i in range(n):
                 rt = e["rt"] if i == 0 else Runtime(e["rt"].device, e["rt"].half, e["rt"].split)
+                rt.pv_products = e["rt"].pv_products
                 enc, mem, head = (copy.copy(e[k]) for k in ("enc", "mem", "head"))
                 enc.rt = mem.rt = head.rt = rt
                 if getattr(enc, "readout", None) is not None:
@@ -195,5 +198,5 @@ class DepthAnythingV2(_EngineOwner):
         """depth_anything_v2.py:67-92."""
         rt = self._engines()["rt"]
         h, w = raw_image.shape[:2]
-        img = torch.from_numpy(np.ascontiguousarray(raw_image[:, :, ::-1])).to(rt.device).float() / 255.0
-        return self.preprocess(rt, img[None], input_size), (h, w)
+        img = torch.from_numpy(np.ascontiguousarray(raw_image)).to(rt.device)   # BGR u8: the kernel swaps the channels
+        return self.preprocess(rt, img[None], input_size, swap_rb=True), (h, w)

@@ -114,8 +114,7 @@ class EncoderEngine:
             probe(-1, tok)
         # 8-bit cross-term path: large batches only (its kernel has 256 x 256 tiles: M >= 4096 keeps every launch near a
         # round of the chip or more), with the default attention (the only producer of the 8-bit output planes)
-        use8 = (self.x8 and M >= 4096 and q8 is not None and abi.lib.vdn_flash_attn_get_pv_products() != 3
-                and abi.lib.vdn_flash_attn_get_stream() == 2)
+        use8 = self.x8 and M >= 4096 and q8 is not None and rt.pv_products != 3
         if use8:
             from .runtime import HL
             # activations between the linears as K-tile-major planes: fp16 hi + e5m2 (value, remainder) — no fp16 lo plane

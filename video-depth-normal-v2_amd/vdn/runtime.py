@@ -83,6 +83,10 @@ class Runtime:
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self.cu_hint = 0  # vdn_gemm_desc.cu_hint: 0 = whole chip; lanes that co-run set their share
+        # MFMA products per P V term of vdn_flash_attn (include/vdn.h), per call: 1 (default) | 2 | 3. Decides which planes the
+        # projections write (v_dst / qk_dst) and which kernel every attention launch of this runtime takes — one value per model.
+        self.pv_products = int(os.environ.get("VDN_ATTN_PV", "1"))
+        assert self.pv_products in (1, 2, 3), self.pv_products
         self.timing: Optional[list] = None  # bench.py: [(tag, start_event, end_event, flop)] for tagged launches
 
     # ------------------------------------------------------------------ memory
@@ -112,17 +116,17 @@ class Runtime:
 
     def v_dst(self, vt: HL) -> HL:
         """Destination planes of a V^T head split: when the attention in use is the one-product P V kernel (fp16 split planes
-        with the 8-bit Q / K planes, vdn_flash_attn_set_pv_products(1), generated stream) nothing ever reads V^T's lo plane,
+        with the 8-bit Q / K planes, pv_products 1) nothing ever reads V^T's lo plane,
         so the projection does not write it — 2-byte scattered stores: 218 -> 210 us on the batch-8 QKV GEMM."""
         if (vt.lo is not None and self.half == torch.float16 and os.environ.get("VDN_ATTN_QK8", "1") != "0"
-                and abi.lib.vdn_flash_attn_get_pv_products() == 1 and abi.lib.vdn_flash_attn_get_stream() == 2):
+                and self.pv_products == 1):
             return HL(vt.hi, None)
         return vt
 
     def qk_dst(self, t: HL, t8) -> HL:
         """Destination planes of a Q / K head split: with the 8-bit planes (t8) the attention reads e5m2(lo 2^10) and never
         the fp16 lo plane, so the projection does not write it."""
-        if abi.lib.vdn_flash_attn_get_pv_products() == 3:
+        if self.pv_products == 3:
             return t   # the 3-product P V kernel (flash_attn_kernel<.., false, false>) takes its score cross terms from the fp16 lo planes
         return HL(t.hi, None) if (t8 is not None and t.lo is not None) else t
 
@@ -220,6 +224,8 @@ class Runtime:
             d.out8 = out8.data_ptr()
         d.a_kt, d.w_kt, d.out_kt = int(a_kt), int(w_kt), int(out_kt)   # K-tile-major planes (include/vdn.h)
         d.cu_hint = self.cu_hint
+        if abi.OVERRIDE is not None:   # per-launch kernel-selection knobs (tests / tools); the library itself is stateless
+            d.tuning = C.addressof(abi.OVERRIDE)
         if self.split:  # split-K scratch for launches whose tile grid covers a fraction of the chip (include/vdn.h)
             ws = self.buf("splitk_ws", (32 * 1024 * 1024,), torch.float32)
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -242,7 +248,7 @@ class Runtime:
         out8 / out_kt: e5m2 planes of the output and the K-tile-major layout for the 8-bit cross-term GEMM that follows."""
         (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
         self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
-                     vl, ol, self._p(q8), self._p(k8), self._p(out8), int(out_kt), B, H, nq, nq_pad, nk, nk_pad, scale, tag=tag,
+                     vl, ol, self._p(q8), self._p(k8), self._p(out8), int(out_kt), B, H, nq, nq_pad, nk, nk_pad, scale, self.pv_products, tag=tag,
                      flop=4.0 * B * H * nq * nk * 64)
 
     def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
@@ -314,6 +320,15 @@ class Runtime:
 
     def bicubic(self, src, dst, ih: int, iw: int, oh: int, ow: int, Cn: int, scale_rows: float, scale_cols: float):
         self._launch(abi.lib.vdn_bicubic, src.data_ptr(), dst.data_ptr(), ih, iw, oh, ow, Cn, scale_rows, scale_cols)
+
+    def preprocess_u8(self, frames_u8: torch.Tensor, H: int, W: int, mean, std, swap_rb: bool = False) -> torch.Tensor:
+        """u8 [n,h,w,3] on the device -> normalised f32 [n,3,H,W] (cubic resize + /255 + mean / std), one launch."""
+        n, h, w, _ = frames_u8.shape
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+        out = torch.empty((n, 3, H, W), dtype=torch.float32, device=self.device)
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        self._launch(abi.lib.vdn_preprocess, frames_u8.data_ptr(), n, h, w, int(swap_rb), out.data_ptr(), H, W, m3, s3)
+        return out
 
     def add_vec(self, x, vec, alpha: float, y, rows: int, Cn: int):
         self._launch(abi.lib.vdn_add_vec, x.data_ptr(), vec.data_ptr(), alpha, y.data_ptr(), rows, Cn)

@@ -182,8 +182,7 @@ class VideoDepthAnything(_EngineOwner):
     def preprocess_frames(self, frames: np.ndarray, input_size: int) -> torch.Tensor:
         """u8 RGB [n,h,w,3] -> normalised f32 [n,3,H,W] on the device (video_depth.py:73-99)."""
         rt = self._engines()["rt"]
-        dev = torch.from_numpy(np.ascontiguousarray(frames)).to(rt.device).float() / 255.0
-        return self.preprocess(rt, dev, input_size)
+        return self.preprocess(rt, torch.from_numpy(np.ascontiguousarray(frames)).to(rt.device), input_size)
 
     def resize_depth(self, d: torch.Tensor, fh: int, fw: int) -> torch.Tensor:
         """[n,H,W] -> [n,fh,fw], bilinear align_corners (video_depth.py:111)."""
