@@ -171,6 +171,11 @@ typedef struct vdn_gemm_desc {
    *           i.e. as the a_kt operand of the next GEMM (bias + GELU / plain half-plane flavours of the 8-bit kernel only).
    * vdn_layernorm and vdn_flash_attn produce the same layout (their `kt` arguments).                                      */
   int32_t a_kt, w_kt, out_kt;
+  /* 8-bit cross-term kernel: which cross terms this launch accumulates. 0 = both (fp32-faithful, the default);
+   * 1 = without A_lo W_hi^T (A enters as its 16-bit hi plane alone: 2^-12 per activation element);
+   * 2 = without A_hi W_lo^T (W as its hi plane alone). A per-launch precision knob for the per-layer budget of
+   * DESIGN.md §3 / profiles/r03_precision_budget.md; the engines pass 0 unless VDN_X8_TERMS says otherwise.           */
+  int32_t x8_terms;
   const vdn_gemm_tuning* tuning;   /* NULL = the library defaults (vdn_gemm_get_tuning); else this launch's own knobs */
 } vdn_gemm_desc;
 

@@ -76,7 +76,8 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if (((uintptr_t)d.A8 | (uintptr_t)d.W8 | (uintptr_t)d.out8) & 15) return VDN_EALIGN;
   if ((d.A8 || d.W8) && (d.dt != VDN_F16 || d.a_mode != VDN_A_PLAIN || (d.K & 63) || (d.lda != d.K && !d.a_kt))) return VDN_EINVAL;
   if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || (d.ldc & 63))) return VDN_EINVAL;
-  if ((d.a_kt || d.w_kt || d.out_kt) && (!d.A8 || !d.W8)) return VDN_EINVAL;  // K-tile-major planes: the 8-bit cross-term kernel only
+  if ((d.a_kt || d.w_kt || d.out_kt || d.x8_terms) && (!d.A8 || !d.W8)) return VDN_EINVAL;
+  if (d.x8_terms < 0 || d.x8_terms > 2) return VDN_EINVAL;  // K-tile-major planes: the 8-bit cross-term kernel only
   if (d.out_kt && (d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || d.ldc != d.N || (d.N & 63) || d.res1 || d.res2 || d.tab ||
                    d.rowadd || d.gamma || d.row_group > 0 || d.act == VDN_ACT_RELU)) return VDN_EINVAL;
   if (((uintptr_t)d.bias | (uintptr_t)d.gamma | (uintptr_t)d.tab | (uintptr_t)d.res1 | (uintptr_t)d.res2) & 7) return VDN_EALIGN;

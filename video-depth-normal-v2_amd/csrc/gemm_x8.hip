@@ -204,6 +204,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = H::mfma32(hw[ks][j], ha[ks][i], acc[i][j]);
     } else {
+      if (p.x8_terms == (ph == 2 ? 1 : 2)) { __builtin_amdgcn_s_setprio(0); return; }  // this launch drops that cross term (include/vdn.h x8_terms)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll

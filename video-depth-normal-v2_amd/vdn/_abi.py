@@ -38,7 +38,7 @@ class GemmDesc(C.Structure):
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("ksplit", i32),
         ("dst8", vp * 3),
         ("A8", vp), ("W8", vp), ("out8", vp),
-        ("a_kt", i32), ("w_kt", i32), ("out_kt", i32),
+        ("a_kt", i32), ("w_kt", i32), ("out_kt", i32), ("x8_terms", i32),
         ("tuning", vp),
     ]
 

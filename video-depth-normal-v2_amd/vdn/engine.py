@@ -65,6 +65,15 @@ class EncoderEngine:
         if self.x8:
             for blk in self.blocks:
                 blk["x8"] = {k: pack.X8(blk[k]) for k in ("wqkv", "wproj", "wfc1", "wfc2")}
+        # per-layer precision budget (include/vdn.h x8_terms; profiles/r03_precision_budget.md): VDN_X8_TERMS = "fc2=1,proj=1@12-23"
+        # drops a cross term of the named linears (1: A_lo W_hi^T, 2: A_hi W_lo^T), optionally for blocks a..b only
+        self.x8_terms = [dict(qkv=0, proj=0, fc1=0, fc2=0) for _ in self.blocks]
+        for item in filter(None, os.environ.get("VDN_X8_TERMS", "").split(",")):
+            name, val = item.split("=")
+            val, _, rng = val.partition("@")
+            a, b = (int(v) for v in rng.split("-")) if rng else (0, len(self.blocks) - 1)
+            for L in range(a, b + 1):
+                self.x8_terms[L][name] = int(val)
 
     def _pos_for(self, ph: int, pw: int):
         """interpolate_pos_encoding (dinov2.py:179-210): identity for the square 37x37 grid, else bicubic
@@ -114,7 +123,7 @@ class EncoderEngine:
             probe(-1, tok)
         # 8-bit cross-term path: large batches only (its kernel has 256 x 256 tiles: M >= 4096 keeps every launch near a
         # round of the chip or more), with the default attention (the only producer of the 8-bit output planes)
-        use8 = self.x8 and M >= 4096 and q8 is not None and rt.pv_products != 3
+        use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096")) and q8 is not None and rt.pv_products != 3
         if use8:
             from .runtime import HL
             # activations between the linears as K-tile-major planes: fp16 hi + e5m2 (value, remainder) — no fp16 lo plane
@@ -126,18 +135,18 @@ class EncoderEngine:
             hn, att, f1 = rt.hbuf("enc_ln", (M, C)), rt.hbuf("enc_att", (M, C)), rt.hbuf("enc_fc1", (M, Hd))
         for i, b in enumerate(self.blocks):
             if use8:
-                x8 = b["x8"]
+                x8, xt = b["x8"], self.x8_terms[i]
                 rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn_k, out8=hn8, kt=True)
                 rt.gemm(hn_k, HL(x8["wqkv"].hi), M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear",
-                        a8=hn8, w8=x8["wqkv"].p8, **kt)
+                        a8=hn8, w8=x8["wqkv"].p8, x8_terms=xt["qkv"], **kt)
                 rt.flash_attn(q, k, vt, att_k, Bf, Hh, N, npad, N, npad, 64 ** -0.5, tag="enc_attn", q8=q8, k8=k8, out8=att8, out_kt=True)
                 rt.gemm(att_k, HL(x8["wproj"].hi), M, C, C, bias=b["bproj"], gamma=b["ls1"], res1=tok, out=tok, tag="enc_linear",
-                        a8=att8, w8=x8["wproj"].p8, **kt)
+                        a8=att8, w8=x8["wproj"].p8, x8_terms=xt["proj"], **kt)
                 rt.layernorm(tok, M, C, b["n2w"], b["n2b"], 1e-6, out_h=hn_k, out8=hn8, kt=True)
                 rt.gemm(hn_k, HL(x8["wfc1"].hi), M, Hd, C, bias=b["bfc1"], act=GELU, out=f1_k, out8=f18, out_kt=True, tag="enc_linear",
-                        a8=hn8, w8=x8["wfc1"].p8, **kt)
+                        a8=hn8, w8=x8["wfc1"].p8, x8_terms=xt["fc1"], **kt)
                 rt.gemm(f1_k, HL(x8["wfc2"].hi), M, C, Hd, bias=b["bfc2"], gamma=b["ls2"], res1=tok, out=tok, tag="enc_linear",
-                        a8=f18, w8=x8["wfc2"].p8, **kt)
+                        a8=f18, w8=x8["wfc2"].p8, x8_terms=xt["fc2"], **kt)
             else:
                 rt.layernorm(tok, M, C, b["n1w"], b["n1b"], 1e-6, out_h=hn)
                 rt.gemm(hn, b["wqkv"], M, 3 * C, C, bias=b["bqkv"], store=abi.ST_HEADS, heads=heads, tag="enc_linear")
@@ -509,6 +518,13 @@ class MemoryEngine:
                 nw=pack.f32(b.norm.weight), nb=pack.f32(b.norm.bias),
                 w1=pack.linear(b.pwconv1.weight, h), b1=pack.f32(b.pwconv1.bias),
                 w2=pack.linear(b.pwconv2.weight, h), b2=pack.f32(b.pwconv2.bias), g=pack.f32(b.gamma)))
+        # 8-bit cross terms for the plain linears of the memory attention and the memory encoder (as in EncoderEngine)
+        self.x8 = rt.split and rt.half == torch.float16 and C % 64 == 0 and os.environ.get("VDN_X8", "1") != "0"
+        if self.x8:
+            for L in self.layers:
+                L["x8"] = {k: pack.X8(L[k]) for k in ("wqkv", "wso", "wq", "wco", "w1", "w2")}
+            for cx in self.cx:
+                cx["x8"] = {k: pack.X8(cx[k]) for k in ("w1", "w2")}
         # Bank state shared by every lane copy of this engine (DepthAnythingV2._stream_lanes): ONE ring for the whole
         # batch, lane i of n works on batch rows [i B/n, (i+1) B/n) of it, so laned and single-lane calls see the
         # same memory and `count` advances once per forward (commit()).
@@ -602,6 +618,29 @@ class MemoryEngine:
         sh = dict(dst=[rt.qk_dst(q, q8), rt.qk_dst(k, k8), rt.v_dst(vt)], dst8=[q8, k8, None], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
                   tokens=P, tpad=pp)
         qh = dict(dst=[rt.qk_dst(q, q8)], dst8=[q8], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
+        use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096")) and q8 is not None and rt.pv_products != 3
+        if use8:   # K-tile-major fp16 hi + e5m2 planes between the linears (no fp16 lo plane), as in EncoderEngine.run
+            from .runtime import HL
+            n_k, n8 = HL(rt.buf("ma_n_kt", (M, C), rt.half)), rt.buf("ma_n8", (2, M, C), torch.uint8)
+            att_k, att8 = HL(rt.buf("ma_att_kt", (M, C), rt.half)), rt.buf("ma_att8", (2, M, C), torch.uint8)
+            h2_k, h28 = HL(rt.buf("ma_h2_kt", (M, 2 * C), rt.half)), rt.buf("ma_h28", (2, M, 2 * C), torch.uint8)
+            kt = dict(a_kt=True, w_kt=True)
+            for l, L in enumerate(self.layers):
+                x8 = L["x8"]
+                rt.layernorm(x, M, C, L["n1w"], L["n1b"], 1e-5, out_h=n_k, out8=n8, kt=True)
+                rt.gemm(n_k, HL(x8["wqkv"].hi), M, 3 * C, C, bias=L["bqkv"], store=abi.ST_HEADS, heads=sh, a8=n8, w8=x8["wqkv"].p8, **kt)
+                rt.flash_attn(q, k, vt, att_k, B, Hh, P, pp, P, pp, 0.125, q8=q8, k8=k8, out8=att8, out_kt=True)
+                rt.gemm(att_k, HL(x8["wso"].hi), M, C, C, bias=L["bso"], res1=x, out=x, a8=att8, w8=x8["wso"].p8, **kt)
+                rt.layernorm(x, M, C, L["n2w"], L["n2b"], 1e-5, out_h=n_k, out8=n8, kt=True, addvec=self.curr_pos, alpha=1.0)
+                rt.gemm(n_k, HL(x8["wq"].hi), M, C, C, bias=L["bq"], store=abi.ST_HEADS, heads=qh, a8=n8, w8=x8["wq"].p8, **kt)
+                rt.flash_attn(q, ks[l], vs[l], att_k, B, Hh, P, pp, nk, nk_pad, 0.125, q8=q8, k8=k8s[l], out8=att8, out_kt=True)
+                rt.gemm(att_k, HL(x8["wco"].hi), M, C, C, bias=L["bco"], res1=x, out=x, a8=att8, w8=x8["wco"].p8, **kt)
+                rt.layernorm(x, M, C, L["n3w"], L["n3b"], 1e-5, out_h=n_k, out8=n8, kt=True)
+                rt.gemm(n_k, HL(x8["w1"].hi), M, 2 * C, C, bias=L["b1"], act=GELU, out=h2_k, out8=h28, out_kt=True, a8=n8, w8=x8["w1"].p8, **kt)
+                rt.gemm(h2_k, HL(x8["w2"].hi), M, C, 2 * C, bias=L["b2"], res1=x, out=x, a8=h28, w8=x8["w2"].p8, **kt)
+            out = rt.hbuf("mem_out", (M, C))
+            rt.layernorm(x, M, C, self.nw, self.nb, 1e-5, out_h=out)
+            return out
         for l, L in enumerate(self.layers):
             rt.layernorm(x, M, C, L["n1w"], L["n1b"], 1e-5, out_h=n)
             rt.gemm(n, L["wqkv"], M, 3 * C, C, bias=L["bqkv"], store=abi.ST_HEADS, heads=sh)
@@ -637,8 +676,21 @@ class MemoryEngine:
         n = rt.hbuf("me_n", (M, C))
         h4 = rt.hbuf("me_h4", (M, 4 * C))
         feat = rt.hbuf("mem_feat", (M, C))
+        use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096"))
+        if use8:
+            from .runtime import HL
+            n_k, n8 = HL(rt.buf("me_n_kt", (M, C), rt.half)), rt.buf("me_n8", (2, M, C), torch.uint8)
+            h4_k, h48 = HL(rt.buf("me_h4_kt", (M, 4 * C), rt.half)), rt.buf("me_h48", (2, M, 4 * C), torch.uint8)
         for j, cx in enumerate(self.cx):
             rt.dwconv7(x, d, B, ph, pw, C, cx["wdw"], cx["bdw"])
+            if use8:
+                x8 = cx["x8"]
+                rt.layernorm(d, M, C, cx["nw"], cx["nb"], 1e-6, out_h=n_k, out8=n8, kt=True)
+                rt.gemm(n_k, HL(x8["w1"].hi), M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4_k, out8=h48, out_kt=True, a8=n8, w8=x8["w1"].p8,
+                        a_kt=True, w_kt=True)
+                rt.gemm(h4_k, HL(x8["w2"].hi), M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=(x if j == 0 else feat), a8=h48,
+                        w8=x8["w2"].p8, a_kt=True, w_kt=True)
+                continue
             rt.layernorm(d, M, C, cx["nw"], cx["nb"], 1e-6, out_h=n)
             rt.gemm(n, cx["w1"], M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4)
             rt.gemm(h4, cx["w2"], M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=(x if j == 0 else feat))

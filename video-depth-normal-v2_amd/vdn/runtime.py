@@ -160,7 +160,7 @@ class Runtime:
              conv: Optional[dict] = None, relu_a: bool = False, store: int = abi.ST_PLAIN, row_group: int = 0,
              row_skip: int = 0, heads: Optional[dict] = None, convt: Optional[dict] = None, tag: Optional[str] = None,
              a8: Optional[torch.Tensor] = None, w8: Optional[torch.Tensor] = None, out8: Optional[torch.Tensor] = None,
-             a_kt: bool = False, w_kt: bool = False, out_kt: bool = False):
+             a_kt: bool = False, w_kt: bool = False, out_kt: bool = False, x8_terms: int = 0):
         d = abi.GemmDesc()
         d.dt = self.dt
         d.M, d.N, d.K = M, N, K
@@ -223,6 +223,7 @@ class Runtime:
         if out8 is not None:
             d.out8 = out8.data_ptr()
         d.a_kt, d.w_kt, d.out_kt = int(a_kt), int(w_kt), int(out_kt)   # K-tile-major planes (include/vdn.h)
+        d.x8_terms = int(x8_terms)
         d.cu_hint = self.cu_hint
         if abi.OVERRIDE is not None:   # per-launch kernel-selection knobs (tests / tools); the library itself is stateless
             d.tuning = C.addressof(abi.OVERRIDE)
