@@ -222,9 +222,11 @@ int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* o
 
 /* Temporal attention over <=64 frames per (pixel, head) (32 in the 32-frame windows, 64 in the v5 refiner): qkv half [(b f), D, 3c] packed
  * [q | k | v], out half [(b f), D, c]. Replaces motion_module/attention.py:182-211 (_attention)
- * with the rearranges of motion_module.py:255,320.                                              */
+ * with the rearranges of motion_module.py:255,320. rope_cs (pe = 'rope', motion_module.py:236-240,279-282; NULL for 'ape',
+ * whose position term enters before the projections): f32 [T, c/2, 2] = (cos, sin)(t * 10000^(-2i/c)); adjacent channel
+ * pairs (2i, 2i+1) of q and k are rotated by their frame's angles on load (attention.py:403-429).                       */
 int vdn_temporal_attn(int dt, const void* qkv, void* out, const void* qkv_lo, void* out_lo, int Bv, int T, int D,
-                      int c, int heads, float scale, vdn_stream stream);
+                      int c, int heads, float scale, const float* rope_cs, vdn_stream stream);
 
 /* GroupNorm over NHWC half [F, HW, C] (fp32 stats per (frame, group)); `partial` is
  * f32 [F, nsplit, groups, 2] scratch. Replaces motion_module.py:112 (32 groups, eps 1e-6).       */

@@ -18,6 +18,8 @@ def _product(which, enc, precision=None):
     import vdn
     cls = vdn.DepthAnythingV2 if which[0] == "A" else vdn.VideoDepthAnything
     flags = dict(use_bn=True, use_clstoken=True) if which.endswith("f") else {}   # "Af" / "Bf": the two optional constructor flags
+    if which == "Br":
+        flags = dict(pe="rope")
     m = cls(**dict(vdn.MODEL_CONFIGS[enc], **flags))
     m.load_state_dict(synth_sd(which, enc), strict=True)
     if precision:
@@ -264,6 +266,12 @@ def test_fp16_plane_range_is_wide_and_its_overflow_is_loud():
 
 def test_B_vits_checkpoint_like_weights():
     _clip_B("B_vits_518_heavy", "vits", use_oracle=True, which="Bh")
+
+
+def test_B_pe_rope():
+    """VideoDepthAnything(pe='rope') (motion_module.py:236-240,279-282): the temporal attention's q / k rotated by the frame
+    index on load (vdn_temporal_attn rope_cs) instead of the additive table; 8-frame clip against the imported reference."""
+    _clip_B("Br_vits_266", "vits", use_oracle=True, which="Br")
 
 
 def test_B_vits_nonsquare_short_clip():

@@ -370,7 +370,7 @@ def test_mask_downsampler_stages(rt):
     close(o2, ref2[:, 0], 1e-4)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 9, 11, 64), (2, 37, 37, 1024), (1, 19, 19, 384)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 11, 64), (2, 37, 37, 1024), (1, 19, 19, 384), (1, 10, 150, 64), (1, 80, 74, 32)])   # W > 73: 64-column tiles
 def test_dwconv7(rt, B, H, W, C):
     """row tiles with a tail (37 = 4 x 8 + 5), column runs with a tail (37 = 9 x 4 + 1), several channel blocks"""
     x = rnd(B, H, W, C, seed=170)

@@ -85,6 +85,10 @@ def test_oracle_use_bn_and_use_clstoken():
     _run_B("Bf_vits_266", "vits", which="Bf")
 
 
+def test_oracle_B_pe_rope():
+    _run_B("Br_vits_266", "vits", which="Br")
+
+
 def test_oracle_B_vits_full_window():
     _run_B("B_vits_518", "vits")
 

@@ -200,7 +200,8 @@ def gen_B(enc: str, H: int, W: int, T: int, keep: list, sub: int, name: str, fla
     torch.manual_seed(0)
     model = VideoDepthAnything(**cfg).eval()
     sd, shapes = load_synth(model, heavy=heavy)
-    with open(os.path.join(GOLD, f"schema_B{'f' if flags else ''}_{enc}.json"), "w") as f:
+    tag = "r" if (flags or {}).get("pe") == "rope" else ("f" if flags else "")
+    with open(os.path.join(GOLD, f"schema_B{tag}_{enc}.json"), "w") as f:
         json.dump({"params": [[k, list(s)] for k, s in shapes],
                    "buffers": [[k, list(v.shape)] for k, v in model.named_buffers()]}, f)
     x = make_inputs(T, H, W).reshape(1, T, 3, H, W)
@@ -438,6 +439,8 @@ JOBS = {
     # checkpoint-like weights (vdn/synth.heavy_overlay): outlier channels, LayerScale over two decades, peaked heads, 1e3-1e4 MLP units
     "A_vitl_518_heavy": lambda: gen_A("vitl", 518, 518, 1, 3, [0, 1, 2], 4, "A_vitl_518_heavy", heavy=True),
     "B_vits_518_heavy": lambda: gen_B("vits", 518, 518, 4, [0, 3], 2, "B_vits_518_heavy", heavy=True),
+    # pe = 'rope' (motion_module.py:236-240,279-282): q / k of the temporal attention rotated by the frame index
+    "Br_vits_266": lambda: gen_B("vits", 266, 266, 8, [0, 7], 1, "Br_vits_266", flags=dict(pe="rope")),
     "R5_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5_vits"),
     "R5f_vits": lambda: gen_refiner(5, "vits", 4, 90, 121, "R5f_vits", flags=dict(use_bn=True, use_clstoken=True)),
     "R4_vits": lambda: gen_refiner(4, "vits", 3, 126, 168, "R4_vits"),

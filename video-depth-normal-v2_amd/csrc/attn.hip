@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<
                                                             typename Half<DT>::T* __restrict__ out,
                                                             const typename Half<DT>::T* __restrict__ qkv_lo,
                                                             typename Half<DT>::T* __restrict__ out_lo, int nseq,
-                                                            int Tn, int D, int c, int heads, float scale_log2) {
+                                                            int Tn, int D, int c, int heads, float scale_log2,
+                                                            const float* __restrict__ rope_cs) {
   using HT = Half<DT>;
   using T = typename HT::T;
   using V8 = typename HT::V8;
@@ -502,6 +503,27 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const typename Half<
           if constexpr (SPLIT) {
             bl = *(const V8*)(base_lo + fq * rs + e0);
             al = *(const V8*)(base_lo + fk * rs + c + e0);
+          }
+          if (rope_cs) {  // pe = 'rope' (motion_module.py:279-282): pairs (2i, 2i+1) of the c channels rotate with the frame index
+            const size_t pair0 = (size_t)(head * dh + e0) >> 1;
+            auto rot = [&](V8& hi, V8& lo, int frame) {
+              const float* cs = rope_cs + ((size_t)frame * (c >> 1) + pair0) * 2;
+#pragma unroll
+              for (int j = 0; j < 8; j += 2) {
+                const float x0 = (float)hi[j] + (SPLIT ? (float)lo[j] : 0.f), x1 = (float)hi[j + 1] + (SPLIT ? (float)lo[j + 1] : 0.f);
+                const float cc = cs[j], ss = cs[j + 1];
+                const float y0 = x0 * cc - x1 * ss, y1 = x0 * ss + x1 * cc;
+                if constexpr (SPLIT) {
+                  T h0, h1, l0, l1;
+                  split2_rtz(y0, y1, h0, h1, l0, l1);
+                  hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
+                } else {
+                  hi[j] = (T)y0; hi[j + 1] = (T)y1;
+                }
+              }
+            };
+            rot(bq, bl, fq);
+            rot(a, al, fk);
           }
         }
         s[kb] = HT::mfma32(a, bq, s[kb]);
@@ -711,12 +733,12 @@ int flash_launch(const void* Q, const void* K, const void* Vt, void* out, const 
 
 template <int DT>
 int temporal_launch(const void* qkv, void* out, const void* qkv_lo, void* out_lo, int nseq, int T, int D, int c, int heads,
-                    float sl2, hipStream_t s) {
+                    float sl2, const float* rope_cs, hipStream_t s) {
   using TT = typename Half<DT>::T;
   const dim3 grid((nseq + 3) / 4);
 #define VDN_TA(SP, NB_)                                                                                          \
   hipLaunchKernelGGL((temporal_attn_kernel<DT, SP, NB_>), grid, dim3(256), 0, s, (const TT*)qkv, (TT*)out,       \
-                     (const TT*)(SP ? qkv_lo : nullptr), (TT*)(SP ? out_lo : nullptr), nseq, T, D, c, heads, sl2)
+                     (const TT*)(SP ? qkv_lo : nullptr), (TT*)(SP ? out_lo : nullptr), nseq, T, D, c, heads, sl2, rope_cs)
   if (qkv_lo) {
     if (T <= 32) VDN_TA(true, 1); else VDN_TA(true, 2);
   } else {
@@ -753,7 +775,7 @@ extern "C" int vdn_flash_attn(int dt, const void* Q, const void* K, const void* 
 }
 
 extern "C" int vdn_temporal_attn(int dt, const void* qkv, void* out, const void* qkv_lo, void* out_lo, int Bv, int T,
-                                 int D, int c, int heads, float scale, vdn_stream stream) {
+                                 int D, int c, int heads, float scale, const float* rope_cs, vdn_stream stream) {
   if (!qkv || !out || Bv <= 0 || T <= 0 || T > 64 || D <= 0 || heads <= 0 || c % heads) return VDN_EINVAL;
   if ((qkv_lo == nullptr) != (out_lo == nullptr)) return VDN_EINVAL;
   const int dh = c / heads;
@@ -762,8 +784,8 @@ extern "C" int vdn_temporal_attn(int dt, const void* qkv, void* out, const void*
   const int nseq = Bv * D * heads;
   const float sl2 = scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;
-  if (dt == VDN_F16) return temporal_launch<VDN_F16>(qkv, out, qkv_lo, out_lo, nseq, T, D, c, heads, sl2, s);
-  if (dt == VDN_BF16) return temporal_launch<VDN_BF16>(qkv, out, qkv_lo, out_lo, nseq, T, D, c, heads, sl2, s);
+  if (dt == VDN_F16) return temporal_launch<VDN_F16>(qkv, out, qkv_lo, out_lo, nseq, T, D, c, heads, sl2, rope_cs, s);
+  if (dt == VDN_BF16) return temporal_launch<VDN_BF16>(qkv, out, qkv_lo, out_lo, nseq, T, D, c, heads, sl2, rope_cs, s);
   return VDN_EUNSUPPORTED;
 }
 

@@ -329,16 +329,20 @@ __global__ __launch_bounds__(128) void mask_down2_kernel(const float* __restrict
 constexpr int DW_TH = 8, DW_CB = 32, DW_PS = 36;  // rows per tile, channels per block, padded pixel stride (floats)
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
                                                       int W, int C, const float* __restrict__ w,
-                                                      const float* __restrict__ bias) {
+                                                      const float* __restrict__ bias, int WT) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sw = (float*)smem;                 // [49][32]
-  float* sx = sw + 49 * DW_CB;              // [DW_TH + 6][W + 6][DW_PS]  (zero halo of 3 columns on both sides)
-  const int cblocks = C / DW_CB, rtiles = (H + DW_TH - 1) / DW_TH;
+  float* sx = sw + 49 * DW_CB;              // [DW_TH + 6][WT + 6][DW_PS]  (halo of 3 columns on both sides, zero outside the image)
+  // WT: columns per tile (the whole row when it fits the LDS, else 64-column tiles: maps wider than 73 pixels)
+  const int cblocks = C / DW_CB, rtiles = (H + DW_TH - 1) / DW_TH, ctiles = (W + WT - 1) / WT;
   int bid = blockIdx.x;
   const int cb = (bid % cblocks) * DW_CB;
   bid /= cblocks;
+  const int x0 = (bid % ctiles) * WT;
+  bid /= ctiles;
   const int oy0 = (bid % rtiles) * DW_TH, b = bid / rtiles;
-  const int WP = W + 6;
+  const int Wt = (W - x0) < WT ? (W - x0) : WT;   // columns of this tile
+  const int WP = WT + 6;
   for (int i = threadIdx.x; i < 49 * (DW_CB / 4); i += 256) {
     const int t = i / (DW_CB / 4), v = i - t * (DW_CB / 4);
     *(f32x4*)(sw + t * DW_CB + v * 4) = *(const f32x4*)(w + (size_t)t * C + cb + v * 4);
@@ -347,17 +351,17 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
     const int v = i % (DW_CB / 4);
     const int p = i / (DW_CB / 4);
     const int r = p / WP, cx = p - r * WP;
-    const int iy = oy0 - 3 + r, ix = cx - 3;
+    const int iy = oy0 - 3 + r, ix = x0 + cx - 3;
     f32x4 val = {0.f, 0.f, 0.f, 0.f};
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = *(const f32x4*)(x + (((size_t)b * H + iy) * W + ix) * C + cb + v * 4);
     *(f32x4*)(sx + (size_t)(r * WP + cx) * DW_PS + v * 4) = val;
   }
   __syncthreads();
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3;  // 8 channel quads x 32 run lanes
-  const int runs_per_row = (W + 3) / 4;
+  const int runs_per_row = (Wt + 3) / 4;
   const f32x4 bv = *(const f32x4*)(bias + cb + v * 4);
   for (int run = pl; run < DW_TH * runs_per_row; run += 32) {
-    const int ry = run / runs_per_row, ox0 = (run - ry * runs_per_row) * 4;
+    const int ry = run / runs_per_row, ox0 = (run - ry * runs_per_row) * 4;   // tile-local column
     if (oy0 + ry >= H) break;
     f32x4 acc[4] = {bv, bv, bv, bv};
 #pragma unroll
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-      if (ox0 + o < W) *(f32x4*)(y + (((size_t)b * H + oy0 + ry) * W + ox0 + o) * C + cb + v * 4) = acc[o];
+      if (ox0 + o < Wt) *(f32x4*)(y + (((size_t)b * H + oy0 + ry) * W + x0 + ox0 + o) * C + cb + v * 4) = acc[o];
   }
 }
 
@@ -506,13 +510,13 @@ extern "C" int vdn_dwconv7(const float* x, float* y, int B, int H, int W, int C,
                            vdn_stream stream) {
   if (!x || !y || !w || !bias || B <= 0 || H <= 0 || W <= 0 || C <= 0) return VDN_EINVAL;
   if (C % DW_CB) return VDN_EALIGN;
-  const size_t lds = ((size_t)49 * DW_CB + (size_t)(DW_TH + 6) * (W + 6) * DW_PS) * sizeof(float);
-  if (lds > 160 * 1024) return VDN_EUNSUPPORTED;  // W <= 73
-  static const bool lds_ok = hipFuncSetAttribute((const void*)dwconv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 160 * 1024) == hipSuccess;
-  (void)lds_ok;
-  hipLaunchKernelGGL(dwconv7_kernel, dim3(B * ((H + DW_TH - 1) / DW_TH) * (C / DW_CB)), dim3(256), lds,
-                     (hipStream_t)stream, x, y, B, H, W, C, w, bias);
+  // the whole row per tile while it fits the 160 KiB of LDS (W <= 73: the 37 x 37 grid of 518 x 518 inputs), else 64-column tiles
+  const int WT = ((size_t)49 * DW_CB + (size_t)(DW_TH + 6) * (W + 6) * DW_PS) * sizeof(float) <= 160 * 1024 ? W : 64;
+  const size_t lds = ((size_t)49 * DW_CB + (size_t)(DW_TH + 6) * (WT + 6) * DW_PS) * sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)dwconv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return -(1000 + (int)attr);
+  hipLaunchKernelGGL(dwconv7_kernel, dim3(B * ((H + DW_TH - 1) / DW_TH) * ((W + WT - 1) / WT) * (C / DW_CB)), dim3(256), lds,
+                     (hipStream_t)stream, x, y, B, H, W, C, w, bias, WT);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }

@@ -74,7 +74,7 @@ EXPORTS = {
                                 C.c_int, vp, vp, C.c_int, fp, vp, C.c_int, vp]),
     "vdn_flash_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_float, C.c_int, vp]),
-    "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "vdn_temporal_attn": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp, vp]),
     "vdn_groupnorm": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, fp,
                                 C.c_int, vp]),
     "vdn_upsample_bilinear": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -223,10 +223,21 @@ class TemporalEngine:
         for i in range(2):
             a = blk.attention_blocks[i]
             wqkv, _ = pack.cat_proj([a.to_q.weight, a.to_k.weight, a.to_v.weight], [None, None, None], [0, 0, 0], h)
-            pe64 = a.pos_encoder.pe.detach().double().reshape(-1, c)
+            rope = not hasattr(a, "pos_encoder")   # pe = 'rope' (motion_module.py:236-240): q / k rotated by frame index, no additive term
+            if rope:
+                Tm = a.max_len
+                pe64 = torch.zeros((Tm, c), dtype=torch.float64, device=a.to_q.weight.device)
+                fr = 1.0 / (10000.0 ** (torch.arange(0, c, 2, dtype=torch.float32)[: c // 2] / c))     # attention.py:403-408
+                ang = torch.outer(torch.arange(Tm, dtype=torch.float32), fr)
+                rope_cs = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().to(a.to_q.weight.device)   # [T, c/2, 2]
+            else:
+                pe64 = a.pos_encoder.pe.detach().double().reshape(-1, c)
+                rope_cs = None
             self.att.append(dict(
                 nw=pack.f32(blk.norms[i].weight), nb=pack.f32(blk.norms[i].bias), wqkv=wqkv,
-                pe=pack.f32(a.pos_encoder.pe).reshape(-1, c),
+                pe=None if rope else pack.f32(a.pos_encoder.pe).reshape(-1, c), rope_cs=rope_cs, max_len=pe64.shape[0],
+                # (streaming with 'rope': the reference rotates by freqs_cis[:1] = position 0 = the identity
+                # (motion_module.py:279-282 with a one-frame query), i.e. no position enters: the zero tables below)
                 # streaming mode: W (x + pe[t]) = W x + W pe[t] -> the position term of each projection as a [T, c] table
                 pe_q=(pe64 @ a.to_q.weight.detach().double().t()).float().contiguous(),
                 pe_k=(pe64 @ a.to_k.weight.detach().double().t()).float().contiguous(),
@@ -248,7 +259,7 @@ class TemporalEngine:
         Everything here is per pixel, so `D` may be any subset of a frame's pixels (vdn/dist.py)."""
         rt, c = self.rt, self.c
         M = B * T * D
-        assert T <= self.att[0]["pe"].shape[0], "clip longer than temporal_max_len (motion_module.py:200-213)"
+        assert T <= self.att[0]["max_len"], "clip longer than temporal_max_len (motion_module.py:200-213)"
         hs = rt.fbuf("tm_h", (M, c))
         rt.gemm(g, self.w_in, M, c, c, bias=self.b_in, out=hs)
         n = rt.hbuf("tm_n", (M, c))
@@ -257,7 +268,7 @@ class TemporalEngine:
         for at in self.att:
             rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n, addtab=at["pe"], tab_div=D, tab_mod=T)
             rt.gemm(n, at["wqkv"], M, 3 * c, c, out=qkv)
-            rt.temporal_attn(qkv, a, B, T, D, c, 8, (c // 8) ** -0.5)
+            rt.temporal_attn(qkv, a, B, T, D, c, 8, (c // 8) ** -0.5, rope_cs=at["rope_cs"])
             rt.gemm(a, at["wo"], M, c, c, bias=at["bo"], res1=hs, out=hs)
         rt.layernorm(hs, M, c, self.fnw, self.fnb, 1e-5, out_h=n)
         gg = rt.hbuf("tm_gg", (M, 4 * c))

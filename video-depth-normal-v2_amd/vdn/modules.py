@@ -152,11 +152,13 @@ def dpt_head(in_channels: int, features: int, out_channels, use_bn: bool = False
     return h
 
 
-def _temporal_attention(c, max_len):
+def _temporal_attention(c, max_len, pe_type="ape"):
     a = Holder()
-    pe = Holder()
-    pe.register_buffer("pe", pack.temporal_pe(c, max_len))
-    a.pos_encoder = pe
+    a.max_len = max_len
+    if pe_type == "ape":    # 'rope' (motion_module.py:236-240) has no buffer in the state dict: freqs_cis is a plain attribute there
+        pe = Holder()
+        pe.register_buffer("pe", pack.temporal_pe(c, max_len))
+        a.pos_encoder = pe
     a.to_q = Lin(c, c, bias=False)
     a.to_k = Lin(c, c, bias=False)
     a.to_v = Lin(c, c, bias=False)
@@ -164,13 +166,13 @@ def _temporal_attention(c, max_len):
     return a
 
 
-def temporal_module(c: int, max_len: int) -> nn.Module:
+def temporal_module(c: int, max_len: int, pe_type: str = "ape") -> nn.Module:
     t = Holder()
     tt = Holder()
     tt.norm = Norm(c)
     tt.proj_in = Lin(c, c)
     blk = Holder()
-    blk.attention_blocks = nn.ModuleList([_temporal_attention(c, max_len) for _ in range(2)])
+    blk.attention_blocks = nn.ModuleList([_temporal_attention(c, max_len, pe_type) for _ in range(2)])
     blk.norms = nn.ModuleList([Norm(c) for _ in range(2)])
     ff = Holder()
     g = Holder()
@@ -184,11 +186,12 @@ def temporal_module(c: int, max_len: int) -> nn.Module:
     return t
 
 
-def dpt_head_temporal(in_channels, features, out_channels, num_frames, use_bn: bool = False, use_clstoken: bool = False) -> nn.Module:
+def dpt_head_temporal(in_channels, features, out_channels, num_frames, use_bn: bool = False, use_clstoken: bool = False,
+                      pe: str = "ape") -> nn.Module:
     h = dpt_head(in_channels, features, out_channels, use_bn, use_clstoken)
     h.motion_modules = nn.ModuleList([
-        temporal_module(out_channels[2], num_frames), temporal_module(out_channels[3], num_frames),
-        temporal_module(features, num_frames), temporal_module(features, num_frames)])
+        temporal_module(out_channels[2], num_frames, pe), temporal_module(out_channels[3], num_frames, pe),
+        temporal_module(features, num_frames, pe), temporal_module(features, num_frames, pe)])
     return h
 
 

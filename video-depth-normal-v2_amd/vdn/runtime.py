@@ -252,9 +252,10 @@ class Runtime:
                      vl, ol, self._p(q8), self._p(k8), self._p(out8), int(out_kt), B, H, nq, nq_pad, nk, nk_pad, scale, self.pv_products, tag=tag,
                      flop=4.0 * B * H * nq * nk * 64)
 
-    def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float):
+    def temporal_attn(self, qkv, out, Bv: int, T: int, D: int, c: int, heads: int, scale: float, rope_cs=None):
         (qkv, ql), (out, ol) = _hl(qkv), _hl(out)
-        self._launch(abi.lib.vdn_temporal_attn, self.dt, qkv.data_ptr(), out.data_ptr(), ql, ol, Bv, T, D, c, heads, scale)
+        self._launch(abi.lib.vdn_temporal_attn, self.dt, qkv.data_ptr(), out.data_ptr(), ql, ol, Bv, T, D, c, heads, scale,
+                     self._p(rope_cs))
 
     def temporal_attn_last(self, pool: torch.Tensor, slots, pe_q, pe_k, pe_v, out, HW: int, c: int, scale: float):
         """Newest frame attends over the projected cache: `pool` f32 [ring slots, HW, 3c], `slots` the window's ring-slot

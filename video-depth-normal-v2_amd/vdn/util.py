@@ -101,6 +101,11 @@ def stitch(depth_list: List[np.ndarray], org_len: int) -> np.ndarray:
 _HOST_OUT = {}   # (shape, dtype) -> (pinned tensor, weakref to the ndarray handed out last time)
 
 
+def release_host_buffers():
+    """Drop the pinned result buffers `to_host` keeps for reuse (two 275 MB buffers after 256-frame clips)."""
+    _HOST_OUT.clear()
+
+
 def check_finite(t: torch.Tensor, what: str):
     """Loud range check of a driver's result before it leaves the device (one reduction next to the copy that synchronises
     anyway). 16-bit operand planes are fp16: an activation beyond +-1.3e5 (hi saturates at 65 504, lo carries the next
@@ -117,7 +122,11 @@ def to_host(t: torch.Tensor) -> np.ndarray:
     256-frame clip runs at 6-8 GB/s (35-45 ms, measured on the MI355X box), the same copy into a pinned buffer at 55 GB/s
     (5 ms) — 3 % of a one-GPU clip and a fifth of an 8-GPU one. Page-locking itself costs as much as the slow copy, so the
     buffer is kept and REUSED for the next result of the same shape — but only once the caller has dropped the array it got
-    (a weak reference tells): a result that is still alive is never overwritten, a fresh buffer is pinned instead."""
+    (a weak reference tells): a result that is still alive is never overwritten, a fresh buffer is pinned instead.
+    NOTE for callers of infer_video_depth / infer_video_depth_sharded: the returned array is a VIEW of that pinned buffer
+    (`owndata` is False, `resize` fails); NumPy views and torch.from_numpy keep it alive, a raw pointer / ctypes /
+    memoryview export does not — copy (`arr.copy()`) before dropping the array if you hold such an export. Up to two
+    result shapes stay pinned; `release_host_buffers()` frees them."""
     if not t.is_cuda:
         return t.numpy()
     import weakref

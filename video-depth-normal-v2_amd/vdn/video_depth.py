@@ -15,15 +15,15 @@ class VideoDepthAnything(_EngineOwner):
     def __init__(self, encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], use_bn=False,
                  use_clstoken=False, num_frames=32, pe="ape"):
         super().__init__()
-        if pe != "ape":
-            raise NotImplementedError("pe='rope' is not enabled by any configuration the reference ships")
+        if pe not in ("ape", "rope"):
+            raise NotImplementedError(pe)   # motion_module.py:242
         if encoder not in ("vits", "vitl"):
             raise KeyError(encoder)  # video_depth.py:48-51
         self.intermediate_layer_idx = {"vits": [2, 5, 8, 11], "vitl": [4, 11, 17, 23]}
         self.encoder = encoder
         cfg = modules.ENCODERS[encoder]
         self.pretrained = modules.dinov2(encoder)
-        self.head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames, use_bn, use_clstoken)
+        self.head = modules.dpt_head_temporal(cfg["dim"], features, out_channels, num_frames, use_bn, use_clstoken, pe)
         self._features, self._out_channels = features, list(out_channels)
 
     def _engines(self):
