@@ -110,7 +110,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const char* W8v = (const char*)p.W8;             // e5m2(W); remainder plane at + N ldb bytes
   const size_t a8l = (size_t)p.M * p.K, w8l = (size_t)p.N * p.ldb;
   // issue this wave's 4 pieces of unit (slab, ph) into ring slot `slot` (ph is a compile-time constant)
-  auto issue = [&](int slab, auto phc, int slot) {
+  // which: -1 = all four pieces, 0..3 = one of them (A piece 0, W piece 0, A piece 1, W piece 1): the steady state spreads
+  // them over the gaps of the phase's MFMAs (VDN_X8_DMA_MFMA)
+  auto issue = [&](int slab, auto phc, int slot, int which = -1) {
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 2) return;
     char* ua = smem + slot * X8_U;
@@ -125,8 +127,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (AP == 16 || wave + 8 * i < AP) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
-      X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
+      if (which >= 0 && which != 2 * i && which != 2 * i + 1) continue;
+      if ((which < 0 || which == 2 * i) && (AP == 16 || wave + 8 * i < AP)) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
+      if (which < 0 || which == 2 * i + 1) X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
     }
   };
   // pieces this wave issues per unit: 4, or 3 for waves 4-7 of the 192-row tile (12 A pieces over 8 waves); the counted
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- phase bodies: the fragment READS of a phase and its MFMAs (48 fragment registers either way)
+  const int sc_alo = p.x8_terms == 1 ? 0 : VDN_LO8_E8M0, sc_wlo = p.x8_terms == 2 ? 0 : VDN_LO8_E8M0;
   V8 hw[2][2] = {}, ha[2][NI] = {};  // fp16 phases: [k-step][block]
   i32x8 cw[2] = {}, ca[NI] = {};     // byte phases
   auto reads = [&](auto phc, int slot) {
@@ -188,11 +192,12 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   };
   // fp16 phases: A_hi W_hi^T over a 32-deep unit (2 k-steps x 8 blocks). Byte phases: one cross term over the slab,
   // phase 2 = W8 A_lo8^T, phase 3 = W_lo8 A8^T (the remainder planes carry 2^10; the E8M0 scale of that operand removes it).
-  auto mfmas = [&](auto phc) {
+  auto mfmas = [&](auto phc, auto&& piece) {   // piece(k), k = 0..3: called after a quarter of the phase's MFMAs each (or never)
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 1) {  // keep the fragments live
       if constexpr (ph < 2) { for (int ks = 0; ks < 2; ++ks) { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(hw[ks][j])); for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(ha[ks][i])); } }
       else { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(cw[j])); for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(ca[i])); }
+      for (int k = 0; k < 4; ++k) piece(k);
       return;
     }
     __builtin_amdgcn_s_setprio(1);
@@ -202,15 +207,24 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = H::mfma32(hw[ks][j], ha[ks][i], acc[i][j]);
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = H::mfma32(hw[ks][j], ha[ks][i], acc[i][j]);
+            constexpr int Q = NI;                         // MFMAs per quarter of the 4 NI of this phase
+            const int idx = (ks * NI + i) * 2 + j;
+            if (idx % Q == Q - 1 || (Q == 3 && false)) piece(idx / Q);
+          }
     } else {
-      if (p.x8_terms == (ph == 2 ? 1 : 2)) { __builtin_amdgcn_s_setprio(0); return; }  // this launch drops that cross term (include/vdn.h x8_terms)
+
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, 127, 0, VDN_LO8_E8M0);
-          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, VDN_LO8_E8M0, 0, 127);
+          // sc_alo / sc_wlo: the E8M0 scale of the remainder plane (2^-10), or 0 = 2^-127 when this launch drops that cross
+          // term (include/vdn.h x8_terms): the product then vanishes in the fp32 accumulator, no branch in the loop
+          if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, 127, 0, sc_alo);
+          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, sc_wlo, 0, 127);
+          const int idx = i * 2 + j;                      // 2 NI scaled MFMAs: a piece after every NI / 2 ... spread over 4 points
+          if (NI == 4 ? (idx & 1) == 1 : (idx == 0 || idx == 2 || idx == 3 || idx == 5)) piece(NI == 4 ? idx >> 1 : (idx == 0 ? 0 : idx == 2 ? 1 : idx == 3 ? 2 : 3));
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -244,31 +258,42 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind
 
-  // one phase: [fragment reads of unit n | DMA of unit n + L | counted wait | reads retired] barrier [MFMAs] barrier
-#define X8_PHASE(PC, ISSUE, WAIT)                                      \
-  do {                                                                 \
-    reads(PC, rd_slot);                                                \
-    ISSUE;                                                             \
-    X8_WAIT_UNITS(WAIT);                                               \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
-    __builtin_amdgcn_s_barrier();                                      \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    mfmas(PC);                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    __builtin_amdgcn_s_barrier();                                      \
-    rd_slot = next(rd_slot);                                           \
-    wr_slot = next(wr_slot);                                           \
+  // one phase: [fragment reads of unit n | DMA of unit n + L | counted wait | reads retired] barrier [MFMAs] barrier. At the wait of
+  // phase n the newest unit issued is n + L and everything up to n + 1 must have landed: L - 1 units stay in flight.
+#ifndef VDN_X8_DMA_MFMA
+#define VDN_X8_DMA_MFMA 0   // 1 (A/B builds): the COMPUTING wave issues the 4 pieces in the gaps of its MFMAs — measured neutral
+#endif                      // (block of four 667 vs 662 us, 246 vs 249 frames/s same box): the reading wave issues them, as in gemm_x3_p8_kernel
+#if VDN_X8_DMA_MFMA
+#define X8_EARLY(PH) (void)0
+#define X8_LATE(PH, K) X8_ISSUE(PH, K)
+#else
+#define X8_EARLY(PH) X8_ISSUE(PH, -1)
+#define X8_LATE(PH, K) (void)0
+#endif
+#define X8_PHASE(PC, PH, WAIT)                                                              \
+  do {                                                                                      \
+    reads(PC, rd_slot);                                                                     \
+    X8_EARLY(PH);                                                                           \
+    X8_WAIT_UNITS(WAIT);                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    mfmas(PC, [&](int k) { X8_LATE(PH, k); __builtin_amdgcn_sched_barrier(0); });           \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    rd_slot = next(rd_slot);                                                                \
+    wr_slot = next(wr_slot);                                                                \
   } while (0)
   // phase ph of slab s issues unit 4 s + ph + L = phase (ph + L) & 3 of slab s + (ph + L) / 4
-#define X8_ISSUE(PH) issue(s + ((PH) + X8_L) / 4, std::integral_constant<int, ((PH) + X8_L) & 3>{}, wr_slot)
-  constexpr int WFULL = X8_L - 1;
+#define X8_ISSUE(PH, K) issue(s + ((PH) + X8_L) / 4, std::integral_constant<int, ((PH) + X8_L) & 3>{}, wr_slot, K)
+  constexpr int WFULL = VDN_X8_DMA_MFMA ? X8_L - 2 : X8_L - 1;
   int s = 0;
   // steady state: every phase of slab s issues (the last unit issued is 4 s + 3 + L <= nunits - 1)
   for (; 4 * s + 3 + X8_L <= nunits - 1; ++s) {
-    X8_PHASE(P0, X8_ISSUE(0), WFULL);
-    X8_PHASE(P1, X8_ISSUE(1), WFULL);
-    X8_PHASE(P2, X8_ISSUE(2), WFULL);
-    X8_PHASE(P3, X8_ISSUE(3), WFULL);
+    X8_PHASE(P0, 0, WFULL);
+    X8_PHASE(P1, 1, WFULL);
+    X8_PHASE(P2, 2, WFULL);
+    X8_PHASE(P3, 3, WFULL);
   }
   // tail: the remaining slabs issue only the units that exist; a phase's wait leaves the units beyond n + 1 in flight
   for (; s < nslab; ++s) {
@@ -277,10 +302,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     do {                                                                                                    \
       const int n = n0u + (PH);                                                                             \
       const bool doit = n + X8_L <= nunits - 1;                                                             \
-      const int left = nunits - 2 - n + 0; /* units beyond n + 1 that exist */                              \
-      const int inflight = doit ? X8_L - 1 : (left < X8_L - 1 ? (left < 0 ? 0 : left) : X8_L - 1);          \
+      const int left = nunits - 2 - n; /* units beyond n + 1 that exist */                                  \
+      const int cap = (VDN_X8_DMA_MFMA || !doit) ? X8_L - 2 : X8_L - 1;                                     \
+      const int inflight = (!VDN_X8_DMA_MFMA && doit) ? cap : (left < cap ? (left < 0 ? 0 : left) : cap);   \
       reads(PC, rd_slot);                                                                                   \
-      if (doit) X8_ISSUE(PH);                                                                               \
+      if (doit) X8_EARLY(PH);                                                                               \
       if (inflight >= 3) X8_WAIT_UNITS(3);                                                                  \
       else if (inflight == 2) X8_WAIT_UNITS(2);                                                             \
       else if (inflight == 1) X8_WAIT_UNITS(1);                                                             \
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
       __builtin_amdgcn_s_barrier();                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
-      mfmas(PC);                                                                                            \
+      mfmas(PC, [&](int k) { if (doit) X8_LATE(PH, k); __builtin_amdgcn_sched_barrier(0); });               \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       __builtin_amdgcn_s_barrier();                                                                         \
       rd_slot = next(rd_slot);                                                                              \
@@ -301,6 +327,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #undef X8_TAIL
   }
 #undef X8_ISSUE
+#undef X8_EARLY
+#undef X8_LATE
 #undef X8_PHASE
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
 #if VDN_X8_ABL & 8
