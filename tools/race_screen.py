@@ -28,6 +28,46 @@ for bm in ("256", "192", "128"):
         bad += diff
         print(f"gemm BM={bm} M={M} N={N} K={K}: {diff} of {reps} runs differ", flush=True)
 _abi.set_tuning(force_bm=0)
+# 8-bit cross-term kernel (5-slot ring, counted waits in units, two tile heights): K-tile-major planes, the three hot flavours
+from vdn.runtime import HL
+
+
+def kt16(t, rows, K):
+    return t.reshape(rows, K // 32, 32).permute(1, 0, 2).contiguous()
+
+
+def kt8(t, rows, K):
+    return t.reshape(rows, K // 64, 64).permute(1, 0, 2).contiguous()
+
+
+for bm in (256, 192):
+    _abi.set_tuning(force_bm=bm)
+    for (M, N, K) in ((10960, 4096, 1024), (5480, 1024, 4096), (10960, 1024, 64), (4100, 3072, 192)):
+        a = rt.to_half(torch.randn(M, K, device="cuda"))
+        w = pack.linear(torch.randn(N, K, device="cuda") / math.sqrt(K), rt.prec)
+        a8 = pack.planes8(a)
+        ak, a8k = HL(kt16(a.hi, M, K)), torch.stack([kt8(a8[0], M, K), kt8(a8[1], M, K)]).contiguous()
+        x8 = pack.X8(w)
+        bias = torch.randn(N, device="cuda")
+        kt = dict(a8=a8k, w8=x8.p8, a_kt=True, w_kt=True)
+        oh, o8 = HL(torch.zeros(M, N, dtype=torch.float16, device="cuda")), torch.zeros(2, M, N, dtype=torch.uint8, device="cuda")
+        res0 = torch.randn(M, N, device="cuda")
+        res = res0.clone()
+
+        def run():
+            rt.gemm(ak, HL(x8.hi), M, N, K, out=oh, out8=o8, out_kt=True, bias=bias, act=_abi.ACT_GELU, **kt)
+            res.copy_(res0)
+            rt.gemm(ak, HL(x8.hi), M, N, K, out=res, bias=bias, gamma=bias, res1=res, **kt)
+
+        run()
+        h0, p0, r0 = oh.hi.clone(), o8.clone(), res.clone()
+        diff = 0
+        for _ in range(reps // 2):
+            run()
+            diff += int(not (torch.equal(oh.hi, h0) and torch.equal(o8, p0) and torch.equal(res, r0)))
+        bad += diff
+        print(f"gemm_x8 BM={bm} M={M} N={N} K={K} (GELU planes + residual): {diff} of {reps // 2} runs differ", flush=True)
+_abi.set_tuning(force_bm=0)
 for (B, H, nq, nk) in ((8, 16, 1370, 1370), (4, 16, 1369, 8214), (2, 6, 150, 200), (1, 16, 361, 1369)):
     qp, kp = ceil_to(nq, 64), ceil_to(nk, 64)
     q = rt.to_half(torch.randn(B * H, qp, 64, device="cuda"))
