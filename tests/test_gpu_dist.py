@@ -29,3 +29,41 @@ def test_sharded_clip_equals_single_process_on_real_kernels(ranks, frames, sched
     print("\n".join(lines))
     assert p.returncode == 0 and "REHEARSAL OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
     assert f"schedule {schedule}" in p.stdout
+
+
+def test_rccl_world_of_one_runs_every_collective_of_the_driver():
+    """RCCL itself on the one GPU of the box: backend "nccl", world size 1, with vdn.dist._FORCE_COLLECTIVES so that the
+    driver ISSUES its collectives — the chunked, asynchronous, variable-split all_to_all_single of the tap exchange, the
+    gather of depth slabs, the broadcast of the stitched clip — on a real communicator instead of taking the world-1
+    shortcuts. Same numbers as the single-process driver. (More ranks need more GPUs: the driver's SCALE run.)"""
+    code = r'''
+import os, sys, datetime
+sys.path.insert(0, os.path.join(%r, "video-depth-normal-v2_amd"))
+import numpy as np, torch, torch.distributed as dist
+import vdn, vdn.dist
+from vdn import synth
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29733")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=120))
+vdn.dist._FORCE_COLLECTIVES = True
+model = vdn.VideoDepthAnything(**vdn.MODEL_CONFIGS["vits"])
+sd = model.state_dict(); sd.update(synth.fast_state_dict([(k, tuple(v.shape)) for k, v in model.named_parameters()], 1234))
+model.load_state_dict(sd, strict=True); model = model.to("cuda").eval()
+frames = synth.frames_u8(7, 50, 140, 168)
+os.environ["VDN_ENC_CHUNK"] = "7"
+st = {}
+d, _ = vdn.dist.infer_video_depth_sharded(model, frames, 24, input_size=140, all_ranks=True, stats=st)
+d = d.copy()
+vdn.dist._FORCE_COLLECTIVES = False
+ref, _ = model.infer_video_depth(frames, 24, input_size=140)
+err = float(np.linalg.norm(d - ref) / np.linalg.norm(ref))
+print("RCCL1", err, vdn.dist.COUNTERS["a2a_calls"], st.get("bytes_taps_sent"))
+assert err < 2e-5 and vdn.dist.COUNTERS["a2a_calls"] >= 8, (err, vdn.dist.COUNTERS)
+dist.destroy_process_group()
+print("RCCL1 OK")
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    print(p.stdout[-600:])
+    assert p.returncode == 0 and "RCCL1 OK" in p.stdout, (p.stdout[-1500:], p.stderr[-2500:])

@@ -51,6 +51,13 @@ def _staged(t: torch.Tensor, group=None) -> bool:
 
 
 _FORCE_STAGING = False   # tests/test_dist.py: run the byte staging on CPU tensors too
+# tests/test_gpu_dist.py: issue every collective even in a world of one rank, so that a one-GPU box runs the real RCCL calls
+# (variable-split all_to_all_single with async handles, gather, broadcast) on a real communicator
+_FORCE_COLLECTIVES = False
+
+
+def _collective(P: int) -> bool:
+    return P > 1 or (_FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 def _row_bytes(t: torch.Tensor) -> int:
@@ -249,7 +256,7 @@ class TapExchange:
             end = self.recv_off[c] + sum(self.out_split[c])
             dst = rb[self.recv_off[c]:end]
             self.bytes_sent += (sum(self.in_split[c]) - self.in_split[c][self.r]) * _row_bytes(pl)
-            if self.P > 1:
+            if _collective(self.P):
                 h = all_to_all(dst, sbuf, self.out_split[c], self.in_split[c], self.group, async_op=True)
                 if h is not None:
                     self.handles.append((h, sbuf))   # keep the send buffer alive until the collective has run
@@ -398,7 +405,7 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
     if pieces:
         cat = torch.cat(pieces)
         slab[: cat.shape[0]].copy_(cat)
-    if P > 1:
+    if _collective(P):
         parts = [torch.empty_like(slab) for _ in range(P)] if r == 0 else None
         gather_to(slab, parts, dst=0)
     else:
@@ -427,7 +434,7 @@ def infer_video_depth_sharded(model, frames: np.ndarray, target_fps, input_size:
             dn = allw.cpu().numpy()
             out = torch.from_numpy(util.stitch([dn[w, i] for w in range(len(table)) for i in range(T)], n)).to(dev)
     t0 = mark("stitch", t0)
-    if all_ranks and P > 1:
+    if all_ranks and _collective(P):
         if r != 0:
             out = torch.empty((n, fh, fw), dtype=torch.float32, device=dev)
         out = out.contiguous()
