@@ -77,6 +77,9 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if ((d.A8 || d.W8) && (d.dt != VDN_F16 || d.a_mode != VDN_A_PLAIN || (d.K & 63) || (d.lda != d.K && !d.a_kt))) return VDN_EINVAL;
   if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || (d.ldc & 63))) return VDN_EINVAL;
   if ((d.a_kt || d.w_kt || d.out_kt || d.x8_terms) && (!d.A8 || !d.W8)) return VDN_EINVAL;
+  // the 8-bit kernel addresses a lane's rows with 32-bit byte offsets inside a plane (row-major planes: rows * ld elements)
+  if (d.A8 && d.W8 && ((!d.a_kt && (long)d.M * d.lda >= (1L << 31)) || (!d.w_kt && (long)d.N * d.ldb >= (1L << 31)) || d.M >= (1 << 25) || d.N >= (1 << 25)))
+    return VDN_EUNSUPPORTED;
   if (d.x8_terms < 0 || d.x8_terms > 2) return VDN_EINVAL;  // K-tile-major planes: the 8-bit cross-term kernel only
   if (d.out_kt && (d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || d.ldc != d.N || (d.N & 63) || d.res1 || d.res2 || d.tab ||
                    d.rowadd || d.gamma || d.row_group > 0 || d.act == VDN_ACT_RELU)) return VDN_EINVAL;

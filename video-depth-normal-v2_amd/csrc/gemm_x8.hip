@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const size_t w_rs = p.w_kt ? 64 : (size_t)p.ldb * 2, w_kts = p.w_kt ? (size_t)p.N * 64 : 64;
   const size_t a8_rs = p.a_kt ? 64 : (size_t)p.lda, a8_kts = p.a_kt ? (size_t)p.M * 64 : 64;
   const size_t w8_rs = p.w_kt ? 64 : (size_t)p.ldb, w8_kts = p.w_kt ? (size_t)p.N * 64 : 64;
-  // 32-bit byte offsets of this thread's two pieces (rows clamped; < 2^31: rows * ld <= 2^30 checked on the host)
+  // 32-bit byte offsets of this thread's two pieces (rows clamped; < 2^32: vdn_gemm rejects larger planes)
   unsigned ah_o[2], wh_o[2], a8_o[2], w8_o[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     for (int i = 0; i < 2; ++i) {
       if (which >= 0 && which != 2 * i && which != 2 * i + 1) continue;
       if ((which < 0 || which == 2 * i) && (AP == 16 || wave + 8 * i < AP)) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
+      if constexpr ((VDN_X8_ABL & 16) && ph >= 2) { if (i == 1) continue; }  // timing model of 6-bit planes: 3 pieces per wave
       if (which < 0 || which == 2 * i + 1) X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
     }
   };
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const bool four = AP == 16 || wave < 4;
 #define X8_WAIT_UNITS(K)                                                          \
   do {                                                                            \
-    if (four) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K)) : "memory");      \
+    if constexpr (VDN_X8_ABL & 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((K) == 3 ? 10 : 3 * (K)) : "memory");  \
+    else if (four) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K)) : "memory");      \
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (K)) : "memory");           \
   } while (0)
 
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const int a8_off0 = (wm * (X8_BM / 2) + r) * 64 + (((2 * h) ^ swz) << 4);  // byte operand: chunk 2 h; chunk 2 h + 1 = bit 4 flipped
   const int w8_off0 = X8_H + (wn * 64 + r) * 64 + (((2 * h) ^ swz) << 4);
   auto rd8 = [&](const char* u, int off) {
-    const u32x4 a0 = *(const u32x4*)(u + off), a1 = *(const u32x4*)(u + (off ^ 16));
+    u32x4 a0 = *(const u32x4*)(u + off), a1;
+    if constexpr (VDN_X8_ABL & 16) { const u32x2 t = *(const u32x2*)(u + (off ^ 16)); a1 = u32x4{t[0], t[1], 0u, 0u}; }
+    else a1 = *(const u32x4*)(u + (off ^ 16));
     i32x8 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = (int)a0[e]; v[4 + e] = (int)a1[e]; }
@@ -221,8 +225,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
         for (int j = 0; j < 2; ++j) {
           // sc_alo / sc_wlo: the E8M0 scale of the remainder plane (2^-10), or 0 = 2^-127 when this launch drops that cross
           // term (include/vdn.h x8_terms): the product then vanishes in the fp32 accumulator, no branch in the loop
-          if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, 127, 0, sc_alo);
-          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 1, 1, 0, sc_wlo, 0, 127);
+          constexpr int FM = (VDN_X8_ABL & 16) ? 3 : 1;   // 1 = e5m2; 3 = e3m2 (timing model of 6-bit planes)
+          if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], FM, FM, 0, 127, 0, sc_alo);
+          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], FM, FM, 0, sc_wlo, 0, 127);
           const int idx = i * 2 + j;                      // 2 NI scaled MFMAs: a piece after every NI / 2 ... spread over 4 points
           if (NI == 4 ? (idx & 1) == 1 : (idx == 0 || idx == 2 || idx == 3 || idx == 5)) piece(NI == 4 ? idx >> 1 : (idx == 0 ? 0 : idx == 2 ? 1 : idx == 3 ? 2 : 3));
         }

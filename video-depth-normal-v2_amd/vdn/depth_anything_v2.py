@@ -135,7 +135,7 @@ class DepthAnythingV2(_EngineOwner):
         if self._eng is not None:
             self._eng["mem"].clear()
 
-    def _forward_lane(self, ln, x, _pre_relu):
+    def _forward_lane(self, ln, x, _pre_relu, out):
         rt, enc, mem, head = ln["rt"], ln["enc"], ln["mem"], ln["head"]
         B = x.shape[0]
         taps, last_f32, (ph, pw) = enc.run(x, want_f32_last=True)
@@ -143,12 +143,8 @@ class DepthAnythingV2(_EngineOwner):
         t3 = fm   # the memory bank is updated with fm itself (depth_anything_v2.py:52-54); the readout happens inside the head
         if getattr(enc, "readout", None) is not None:   # use_clstoken: the memory output takes the last tap's readout (dpt.py:119-123)
             t3 = enc.readout.apply(3, fm, enc.cls_last, B, ph * pw, rt.hbuf("ro_fm", (B * ph * pw, enc.C)))
-        depth = head.run([taps[0], taps[1], taps[2], t3], B, ph, pw, relu=not _pre_relu)
-        out = depth.clone()
-        if _pre_relu:
-            depth.clamp_(min=0)
-        mem.update(fm, depth, B, ph, pw)
-        return out
+        head.run([taps[0], taps[1], taps[2], t3], B, ph, pw, relu=not _pre_relu, out=out)   # the depth tail writes this lane's rows of the result
+        mem.update(fm, out.clamp(min=0) if _pre_relu else out, B, ph, pw)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, _pre_relu: bool = False) -> torch.Tensor:
@@ -160,25 +156,25 @@ class DepthAnythingV2(_EngineOwner):
         x = x.to(device=rt.device, dtype=torch.float32).contiguous()
         B, _, H, W = x.shape
         e["mem"].prepare(B, (H // 14) * (W // 14))
+        out = torch.empty((B, H, W), dtype=torch.float32, device=rt.device)   # the one allocation of a forward: its result
         nl = int(os.environ.get("VDN_STREAMS", "2"))
         if nl < 2 or B < int(os.environ.get("VDN_LANE_MIN_BATCH", "4")) or B % nl:
             rt.cu_hint = 0
-            out = self._forward_lane(dict(rt=rt, enc=e["enc"], mem=e["mem"], head=e["head"]), x, _pre_relu)
+            self._forward_lane(dict(rt=rt, enc=e["enc"], mem=e["mem"], head=e["head"]), x, _pre_relu, out)
             e["mem"].commit()
             return out
         lanes = self._stream_lanes(nl)
         for ln in lanes:
             ln["rt"].cu_hint = 256 // nl  # each lane's GEMM tiles are sized for its share of the CUs
         cur = torch.cuda.current_stream(rt.device)
-        outs = []
-        for ln, xs in zip(lanes, x.chunk(nl)):
+        for ln, xs, os_ in zip(lanes, x.chunk(nl), out.chunk(nl)):
             ln["stream"].wait_stream(cur)
             with torch.cuda.stream(ln["stream"]):
-                outs.append(self._forward_lane(ln, xs.contiguous(), _pre_relu))
+                self._forward_lane(ln, xs.contiguous(), _pre_relu, os_)
         for ln in lanes:
             cur.wait_stream(ln["stream"])
         e["mem"].commit()
-        return torch.cat(outs, dim=0)
+        return out
 
     @torch.no_grad()
     def infer_image(self, raw_image: np.ndarray, input_size: int = 518) -> np.ndarray:

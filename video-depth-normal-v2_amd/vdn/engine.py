@@ -418,7 +418,9 @@ class DPTEngine:
         return p
 
     def run(self, taps: List[torch.Tensor], Bf: int, ph: int, pw: int, T: Optional[int] = None, relu: bool = True,
-            exch=None, stream=None):
+            exch=None, stream=None, out: Optional[torch.Tensor] = None):
+        """`out` (f32 [Bf, 14 ph, 14 pw], contiguous): the caller's result tensor, written by the last kernel directly;
+        without it the depth lands in this engine's arena (valid until the next run)."""
         rt, C, F, oc = self.rt, self.C, self.F, self.oc
         P = ph * pw
         pr = []
@@ -460,7 +462,9 @@ class DPTEngine:
         s0 = (2 * s1[0], 2 * s1[1])
         p1 = self._fusion(1, Bf, s1, s0, p2, r1)
         H, W = ph * PATCH, pw * PATCH
-        depth = rt.fbuf("depth", (Bf, H, W))
+        if out is not None:
+            assert out.shape == (Bf, H, W) and out.dtype == torch.float32 and out.is_contiguous(), (out.shape, out.dtype)
+        depth = out if out is not None else rt.fbuf("depth", (Bf, H, W))
         sy, sx = (s0[0] - 1) / max(H - 1, 1), (s0[1] - 1) / max(W - 1, 1)
         if self.oc2_taps is not None and int(17 * sy) + 3 <= 13 and int(17 * sx) + 3 <= 13:
             # resize -> conv3x3 + ReLU -> conv1x1 (+ ReLU) without leaving the chip (the scale is 8/14 for every DPT head);
