@@ -39,13 +39,24 @@ constexpr int X8_WH = 256 * 64;   // bytes of the W half of a unit: 256 rows x 6
 #ifndef VDN_X8_NSLOT
 #define VDN_X8_NSLOT 5
 #endif
+#ifndef VDN_X8_ABL
+#define VDN_X8_ABL 0   // timing-only builds (tools/build_variant.sh): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads, 8 = clock stamps,
+#endif                 // 16 = cross terms in a 6-bit format from 24-KiB units (what e3m2 planes would cost; results meaningless)
 constexpr int X8_NSLOT = VDN_X8_NSLOT;
 constexpr int x8_unit(int bm) { return bm * 64 + X8_WH; }  // 32 KiB (BM 256) or 28 KiB (BM 192)
 constexpr int X8_L = X8_NSLOT - 1;  // issue lead in phases
-#ifndef VDN_X8_ABL
-#define VDN_X8_ABL 0   // timing-only builds (tools/build_variant.sh): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads
-#endif
-
+// DMA instructions one wave issues for the unit of phase ph (`four`: the wave moves 2 A pieces, else 1)
+constexpr int x8_pc(int ph, bool four) {
+  const int a = four ? 2 : 1, w = 2;
+  if ((VDN_X8_ABL & 16) && ph >= 2) return a + 1;
+  return a + w;
+}
+// ... for the k newest units, the newest being the unit of phase `newest`
+constexpr int x8_inflight(int newest, int k, bool four) {
+  int n = 0;
+  for (int t = 0; t < k; ++t) n += x8_pc((newest - t) & 3, four);
+  return n;
+}
 #define X8_GLDS(src, dst)                                                                 \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
@@ -109,10 +120,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const char* A8v = (const char*)p.A8;             // e5m2(A); the remainder plane follows at + M K bytes
   const char* W8v = (const char*)p.W8;             // e5m2(W); remainder plane at + N ldb bytes
   const size_t a8l = (size_t)p.M * p.K, w8l = (size_t)p.N * p.ldb;
-  // issue this wave's 4 pieces of unit (slab, ph) into ring slot `slot` (ph is a compile-time constant)
-  // which: -1 = all four pieces, 0..3 = one of them (A piece 0, W piece 0, A piece 1, W piece 1): the steady state spreads
-  // them over the gaps of the phase's MFMAs (VDN_X8_DMA_MFMA)
-  auto issue = [&](int slab, auto phc, int slot, int which = -1) {
+  // issue this wave's pieces of unit (slab, ph) into ring slot `slot` (ph is a compile-time constant)
+  auto issue = [&](int slab, auto phc, int slot) {
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 2) return;
     char* ua = smem + slot * X8_U;
@@ -127,20 +136,19 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (which >= 0 && which != 2 * i && which != 2 * i + 1) continue;
-      if ((which < 0 || which == 2 * i) && (AP == 16 || wave + 8 * i < AP)) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
+      if (AP == 16 || wave + 8 * i < AP) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
       if constexpr ((VDN_X8_ABL & 16) && ph >= 2) { if (i == 1) continue; }  // timing model of 6-bit planes: 3 pieces per wave
-      if (which < 0 || which == 2 * i + 1) X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
+      X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
     }
   };
-  // pieces this wave issues per unit: 4, or 3 for waves 4-7 of the 192-row tile (12 A pieces over 8 waves); the counted
-  // waits below are in UNITS left in flight
+  // Counted waits: the K newest units may stay in flight, the newest being the unit of phase NEWPH. A wave's DMA instructions
+  // per unit depend on the unit's phase (x8_pc): 2 A + 2 W pieces, 1 + 2 for waves 4-7 of the 192-row tile (12 A pieces over
+  // 8 waves).
   const bool four = AP == 16 || wave < 4;
-#define X8_WAIT_UNITS(K)                                                          \
-  do {                                                                            \
-    if constexpr (VDN_X8_ABL & 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((K) == 3 ? 10 : 3 * (K)) : "memory");  \
-    else if (four) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K)) : "memory");      \
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (K)) : "memory");           \
+#define X8_WAIT(NEWPH, K)                                                                                     \
+  do {                                                                                                        \
+    if (four) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(x8_inflight((NEWPH), (K), true)) : "memory");          \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(x8_inflight((NEWPH), (K), false)) : "memory");              \
   } while (0)
 
   // ---- fragment addresses inside a unit (64-byte rows): 16-byte chunk c of row `row` sits at c ^ ((-(row >> 2)) & 3).
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- phase bodies: the fragment READS of a phase and its MFMAs (48 fragment registers either way)
+  // ---- phase bodies: the fragment READS of a phase and its MFMAs
   const int sc_alo = p.x8_terms == 1 ? 0 : VDN_LO8_E8M0, sc_wlo = p.x8_terms == 2 ? 0 : VDN_LO8_E8M0;
   V8 hw[2][2] = {}, ha[2][NI] = {};  // fp16 phases: [k-step][block]
   i32x8 cw[2] = {}, ca[NI] = {};     // byte phases
@@ -196,12 +204,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   };
   // fp16 phases: A_hi W_hi^T over a 32-deep unit (2 k-steps x 8 blocks). Byte phases: one cross term over the slab,
   // phase 2 = W8 A_lo8^T, phase 3 = W_lo8 A8^T (the remainder planes carry 2^10; the E8M0 scale of that operand removes it).
-  auto mfmas = [&](auto phc, auto&& piece) {   // piece(k), k = 0..3: called after a quarter of the phase's MFMAs each (or never)
+  auto mfmas = [&](auto phc) {
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 1) {  // keep the fragments live
       if constexpr (ph < 2) { for (int ks = 0; ks < 2; ++ks) { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(hw[ks][j])); for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(ha[ks][i])); } }
       else { for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(cw[j])); for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(ca[i])); }
-      for (int k = 0; k < 4; ++k) piece(k);
       return;
     }
     __builtin_amdgcn_s_setprio(1);
@@ -213,12 +220,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[i][j] = H::mfma32(hw[ks][j], ha[ks][i], acc[i][j]);
-            constexpr int Q = NI;                         // MFMAs per quarter of the 4 NI of this phase
-            const int idx = (ks * NI + i) * 2 + j;
-            if (idx % Q == Q - 1 || (Q == 3 && false)) piece(idx / Q);
+            // keep the issue order as written (8 independent accumulators between two MFMAs on the same one): left to itself
+            // the scheduler regroups them and the phase runs ~10 % longer (measured: block of four 720 vs 655 us)
+            if (j == 1) __builtin_amdgcn_sched_barrier(0);
           }
     } else {
-
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -228,8 +234,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
           constexpr int FM = (VDN_X8_ABL & 16) ? 3 : 1;   // 1 = e5m2; 3 = e3m2 (timing model of 6-bit planes)
           if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], FM, FM, 0, 127, 0, sc_alo);
           else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], FM, FM, 0, sc_wlo, 0, 127);
-          const int idx = i * 2 + j;                      // 2 NI scaled MFMAs: a piece after every NI / 2 ... spread over 4 points
-          if (NI == 4 ? (idx & 1) == 1 : (idx == 0 || idx == 2 || idx == 3 || idx == 5)) piece(NI == 4 ? idx >> 1 : (idx == 0 ? 0 : idx == 2 ? 1 : idx == 3 ? 2 : 3));
+          if (j == 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -258,84 +263,67 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     if constexpr (X8_L > 4) pro(4, P0);
   }
   // unit 0 has landed when all but the L - 1 newest units have (short K: fewer units were issued, wait for all)
-  if (nunits >= X8_L) X8_WAIT_UNITS(X8_L - 1);
+  if (nunits >= X8_L) X8_WAIT((X8_L - 1) & 3, X8_L - 1);
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind
 
-  // one phase: [fragment reads of unit n | DMA of unit n + L | counted wait | reads retired] barrier [MFMAs] barrier. At the wait of
-  // phase n the newest unit issued is n + L and everything up to n + 1 must have landed: L - 1 units stay in flight.
-#ifndef VDN_X8_DMA_MFMA
-#define VDN_X8_DMA_MFMA 0   // 1 (A/B builds): the COMPUTING wave issues the 4 pieces in the gaps of its MFMAs — measured neutral
-#endif                      // (block of four 667 vs 662 us, 246 vs 249 frames/s same box): the reading wave issues them, as in gemm_x3_p8_kernel
-#if VDN_X8_DMA_MFMA
-#define X8_EARLY(PH) (void)0
-#define X8_LATE(PH, K) X8_ISSUE(PH, K)
-#else
-#define X8_EARLY(PH) X8_ISSUE(PH, -1)
-#define X8_LATE(PH, K) (void)0
-#endif
-#define X8_PHASE(PC, PH, WAIT)                                                              \
+  // one phase: [fragment reads of unit n | DMA of unit n + L | counted wait | reads retired] barrier
+  // [MFMAs] barrier. At the wait of phase n the newest unit issued is n + L and everything up to n + 1 must have landed:
+  // L - 1 units stay in flight.
+#define X8_PHASE(PC, PH)                                                                    \
   do {                                                                                      \
     reads(PC, rd_slot);                                                                     \
-    X8_EARLY(PH);                                                                           \
-    X8_WAIT_UNITS(WAIT);                                                                    \
+    X8_ISSUE(PH);                                                                           \
+    X8_WAIT(((PH) + X8_L) & 3, X8_L - 1);                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_s_barrier();                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                      \
-    mfmas(PC, [&](int k) { X8_LATE(PH, k); __builtin_amdgcn_sched_barrier(0); });           \
+    mfmas(PC);                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     __builtin_amdgcn_s_barrier();                                                           \
     rd_slot = next(rd_slot);                                                                \
     wr_slot = next(wr_slot);                                                                \
   } while (0)
   // phase ph of slab s issues unit 4 s + ph + L = phase (ph + L) & 3 of slab s + (ph + L) / 4
-#define X8_ISSUE(PH, K) issue(s + ((PH) + X8_L) / 4, std::integral_constant<int, ((PH) + X8_L) & 3>{}, wr_slot, K)
-  constexpr int WFULL = VDN_X8_DMA_MFMA ? X8_L - 2 : X8_L - 1;
+#define X8_ISSUE(PH) issue(s + ((PH) + X8_L) / 4, std::integral_constant<int, ((PH) + X8_L) & 3>{}, wr_slot)
   int s = 0;
   // steady state: every phase of slab s issues (the last unit issued is 4 s + 3 + L <= nunits - 1)
   for (; 4 * s + 3 + X8_L <= nunits - 1; ++s) {
-    X8_PHASE(P0, 0, WFULL);
-    X8_PHASE(P1, 1, WFULL);
-    X8_PHASE(P2, 2, WFULL);
-    X8_PHASE(P3, 3, WFULL);
+    X8_PHASE(P0, 0);
+    X8_PHASE(P1, 1);
+    X8_PHASE(P2, 2);
+    X8_PHASE(P3, 3);
   }
-  // tail: the remaining slabs issue only the units that exist; a phase's wait leaves the units beyond n + 1 in flight
+  // last slab (L = 4: exactly one slab is left and none of its phases issues): the units beyond n + 1 stay in flight, the
+  // newest being the last unit of the launch (phase 3)
+  static_assert(X8_L == 4, "the tail below is written for a lead of one slab");
+#define X8_TAIL(PC, LEFT)                                                                   \
+  do {                                                                                      \
+    reads(PC, rd_slot);                                                                     \
+    if constexpr ((LEFT) > 0) X8_WAIT(3, (LEFT));                                           \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    mfmas(PC);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    rd_slot = next(rd_slot);                                                                \
+  } while (0)
+  // (written as a loop — it runs once — so that the last slab stays a block of its own: in straight-line code the register
+  // allocator places the epilogue's spills between the last MFMAs)
   for (; s < nslab; ++s) {
-    const int n0u = 4 * s;
-#define X8_TAIL(PC, PH)                                                                                   \
-    do {                                                                                                    \
-      const int n = n0u + (PH);                                                                             \
-      const bool doit = n + X8_L <= nunits - 1;                                                             \
-      const int left = nunits - 2 - n; /* units beyond n + 1 that exist */                                  \
-      const int cap = (VDN_X8_DMA_MFMA || !doit) ? X8_L - 2 : X8_L - 1;                                     \
-      const int inflight = (!VDN_X8_DMA_MFMA && doit) ? cap : (left < cap ? (left < 0 ? 0 : left) : cap);   \
-      reads(PC, rd_slot);                                                                                   \
-      if (doit) X8_EARLY(PH);                                                                               \
-      if (inflight >= 3) X8_WAIT_UNITS(3);                                                                  \
-      else if (inflight == 2) X8_WAIT_UNITS(2);                                                             \
-      else if (inflight == 1) X8_WAIT_UNITS(1);                                                             \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-      __builtin_amdgcn_s_barrier();                                                                         \
-      __builtin_amdgcn_sched_barrier(0);                                                                    \
-      mfmas(PC, [&](int k) { if (doit) X8_LATE(PH, k); __builtin_amdgcn_sched_barrier(0); });               \
-      __builtin_amdgcn_sched_barrier(0);                                                                    \
-      __builtin_amdgcn_s_barrier();                                                                         \
-      rd_slot = next(rd_slot);                                                                              \
-      wr_slot = next(wr_slot);                                                                              \
-    } while (0)
-    X8_TAIL(P0, 0);
+    X8_TAIL(P0, 2);
     X8_TAIL(P1, 1);
-    X8_TAIL(P2, 2);
-    X8_TAIL(P3, 3);
-#undef X8_TAIL
+    X8_TAIL(P2, 0);
+    X8_TAIL(P3, 0);
   }
+#undef X8_TAIL
 #undef X8_ISSUE
-#undef X8_EARLY
-#undef X8_LATE
 #undef X8_PHASE
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count of the two groups
+  __builtin_amdgcn_sched_barrier(0);  // nothing of the epilogue is scheduled into the last slab
 #if VDN_X8_ABL & 8
   if (p.splitk_ws && tid == 0 && (blockIdx.x % 37) == 0) {  // a few workgroups report into scratch nothing else reads
     unsigned long long* dbg = (unsigned long long*)p.splitk_ws + (blockIdx.x / 37) * 2;
@@ -434,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       }
   }
 }
-#undef X8_WAIT_UNITS
+#undef X8_WAIT
 #undef X8_GLDS
 
 template <int BM>
