@@ -153,13 +153,19 @@ typedef struct vdn_gemm_desc {
    * 64 bytes of e5m2((v - hi(v)) * 2^10), same token mapping as dst[s]. NULL = not written. Must be NULL for
    * transposed splits. A split with 8-bit planes may leave its dst_lo NULL (the attention then never reads the fp16 lo plane).                                                                                            */
   void* dst8[3];
-  /* 8-bit cross-term planes of the GEMM operands themselves (plain A, VDN_F16, K % 64 == 0; all three optional):
-   * A8 u8 [2, M, K] and W8 u8 [2, N, ldb]: plane 0 = e5m2(v), plane 1 = e5m2((v - hi(v)) * 2^10), same row-major shape
-   * as the fp16 operand (lda == K). When both are given, the kernel accumulates A_hi W_hi^T on fp16 MFMAs and the two cross
-   * terms on the block-scaled 8-bit MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) instead of two more fp16 products; A_lo /
-   * W_lo are then not read. out8: the same planes of a half-precision PLAIN output (u8 [2, M, ldc], ldc % 64 == 0),
-   * written next to out / out_lo for the GEMM that consumes it. vdn_pack_x8 / vdn_layernorm / vdn_flash_attn
-   * (their out8 arguments) produce the planes of weights and of the other activations.                             */
+  /* Cross-term planes of the GEMM operands themselves (plain A, VDN_F16, K % 64 == 0; all three optional). When A8 and W8 are
+   * given, the kernel accumulates A_hi W_hi^T on fp16 MFMAs and the two cross terms A_hi W_lo^T + A_lo W_hi^T on the
+   * block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e3m2 operands: 4.2x the fp16 rate) instead of two more fp16
+   * products; A_lo / W_lo are then not read.
+   *   A8 u8 [2, M, K], W8 u8 [2, N, ldb]: plane 0 describes hi(v), plane 1 the remainder v - hi(v); same row-major shape
+   *   as the fp16 operand (lda == K), in "x6 rows": per row and 64 of K a 64-byte row-slab of two 32-byte HALVES (one per
+   *   K half of the MFMA), each [24 B: 32 e3m2 codes, 6-bit fields, little-endian][1 B: E8M0 scale byte s, value = code
+   *   2^(s - 127)][7 B unused]; s = floor(log2 max|hi| of the half) - 4 + 127 for plane 0 and 10 less for plane 1.
+   *   WHICH 32 columns of the slab a half holds, and in what order, is the producer's choice (vdn_pack_x8 `order`): the
+   *   hardware only needs A and W to agree, so the weight planes are packed in the order of the kernel that writes A.
+   *   out8: the same planes of a half-precision output of the bias + GELU flavour (u8 [2, M, ldc], N == ldc, N % 64 == 0),
+   *   written next to out / out_lo for the GEMM that consumes it (order 1). vdn_pack_x8 / vdn_layernorm / vdn_flash_attn
+   *   (their out8 arguments) produce the planes of weights and of the other activations.                             */
   const void* A8;
   const void* W8;
   void* out8;
@@ -189,8 +195,8 @@ int vdn_gemm(const vdn_gemm_desc* d, vdn_stream stream);
  * sinusoidal PE add of :211 fused as addtab), LayerNorm2d sam2_utils.py:148-153 on NHWC rows.
  *   out_group > 0 drops the first row of every `out_group` rows (the cls token, dinov2.py:312)
  *   and writes the remaining rows compacted.
- *   out8 (VDN_F16, C % 64 == 0, optional): u8 [2, rows, C], e5m2(y) and e5m2((y - hi(y)) 2^10): the A8 planes of the GEMM that
- *   consumes y (out_h_lo may then be NULL). kt != 0: out_h / out_h_lo / out8 are written K-tile-major (vdn_gemm_desc.a_kt). */
+ *   out8 (VDN_F16, C % 64 == 0, optional): u8 [2, rows, C], the x6 rows of y (vdn_gemm_desc.A8; order 0): the A8 planes of the
+ *   GEMM that consumes y (out_h_lo may then be NULL). kt != 0: out_h / out_h_lo / out8 are written K-tile-major (vdn_gemm_desc.a_kt). */
 int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, const float* b, float eps,
                   const float* addvec, float alpha, const float* addtab, int tab_div, int tab_mod,
                   int out_group, void* out_h, void* out_h_lo, int h_dt, float* out_f, void* out8, int kt,
@@ -204,8 +210,8 @@ int vdn_layernorm(const void* x, int x_dt, int rows, int C, const float* w, cons
  *   Q8 / K8 (both or neither; split fp16 planes only): the 8-bit planes vdn_gemm wrote through dst8
  *   (u8 [BH, n_pad, 128]); the two cross terms K_hi Q_lo^T + K_lo Q_hi^T of the scores then run on the block-scaled
  *   8-bit MFMA (e5m2, 2.3x the fp16 rate) instead of two fp16 products; logits stay within ~1e-5. NULL = 3 fp16 products.
- *   out8 (with Q8 / K8 only, optional): u8 [2, B nq, H 64], e5m2(out) and e5m2((out - hi(out)) 2^10): the A8 planes of the
- *   projection that consumes the output (out_lo may then be NULL); out_kt != 0: out / out_lo / out8 are written K-tile-major
+ *   out8 (with Q8 / K8 only, optional): u8 [2, B nq, H 64], the x6 rows of the output (vdn_gemm_desc.A8; order 2): the A8 planes of
+ *   the projection that consumes the output (out_lo may then be NULL); out_kt != 0: out / out_lo / out8 are written K-tile-major
  *   with rows = B nq (vdn_gemm_desc.a_kt).                                                                                 */
 int vdn_flash_attn(int dt, const void* Q, const void* K, const void* Vt, void* out, const void* Q_lo,
                    const void* K_lo, const void* Vt_lo, void* out_lo, const void* Q8, const void* K8, void* out8, int out_kt,
@@ -365,10 +371,16 @@ int vdn_pack_rows(int kind, int d0, int d1, int d2);  /* rows of the packed plan
 int vdn_pack_ldb(int kind, int d0, int d1, int d2);   /* plane stride in elements */
 int vdn_pack_weight(int dt, int kind, const float* w, int d0, int d1, int d2, void* hi, void* lo, int ldb, vdn_stream stream);
 int vdn_pack_bias(int kind, const float* b, int d0, int d1, int d2, float* out, vdn_stream stream);
-/* Operand planes of the 8-bit cross-term GEMM (vdn_gemm_desc.W8 / w_kt) from fp16 split planes (hi, lo) [rows, ld] as
- * vdn_pack_weight wrote them (ld % 64 == 0): planes8 = u8 [2, rows, ld] = e5m2(hi + lo), e5m2(lo 2^10); kt != 0 stores both
- * K-tile-major ([ld/64][rows][64] each) and, if hi_kt is given, the hi plane again as [ld/32][rows][32].                   */
-int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, vdn_stream stream);
+/* Operand planes of the cross-term GEMM (vdn_gemm_desc.A8 / W8) from fp16 split planes (hi, lo) [rows, ld] as vdn_pack_weight
+ * wrote them (ld % 64 == 0): planes8 = u8 [2, rows, ld], the x6 rows of hi and of lo; kt != 0 stores both K-tile-major
+ * ([ld/64][rows][64] each) and, if hi_kt is given, the hi plane again as [ld/32][rows][32].
+ * order = which columns of a 64-wide slab half h holds at stream position p (both operands of a GEMM must use the order of
+ * the kernel that writes its A planes):
+ *   0  col = 32 h + p                                            A from vdn_layernorm or from this function
+ *   1  col = 32 (p >> 4) + 16 ((p >> 3) & 1) + 8 h + (p & 7)     A from vdn_gemm out8 (bias + GELU)
+ *   2  col = 32 (p >> 4) + 8 ((p >> 2) & 3) + 4 h + (p & 3)      A from vdn_flash_attn out8                              */
+int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, int order,
+                vdn_stream stream);
 
 /* Workspace sizing (the library allocates nothing): bytes of split-K scratch worth passing as vdn_gemm_desc.splitk_ws
  * for this descriptor (0 = the shape never splits), and the partial-sum buffer of vdn_groupnorm.

@@ -996,8 +996,8 @@ def test_pack_weight_abi_against_torch_layouts(rt3):
 
 @pytest.mark.parametrize("M,N,K", [(2740, 1024, 1024), (1370 * 2 + 77, 3072, 384), (2048, 512, 4096)])
 def test_x8_gemm_cross_terms_on_the_8bit_mfma(rt3, M, N, K, tune):
-    """gemm_x8_kernel: A_hi W_hi^T on fp16 MFMAs + the two cross terms on the block-scaled e5m2 MFMA, from the 8-bit
-    operand planes; ragged M (tile tail), 1 / 6 / 64 slabs; against fp64, against the 3-product kernel, bitwise repeatable."""
+    """gemm_x8_kernel: A_hi W_hi^T on fp16 MFMAs + the two cross terms on the block-scaled e3m2 MFMA, from the planes of
+    6-bit rows; ragged M (tile tail), 1 / 6 / 64 slabs; against fp64, against the 3-product kernel, bitwise repeatable."""
     from vdn import pack, _abi
     a = rnd(M, K, seed=980)
     w = rnd(N, K, seed=981, scale=1 / math.sqrt(K))
@@ -1017,8 +1017,8 @@ def test_x8_gemm_cross_terms_on_the_8bit_mfma(rt3, M, N, K, tune):
     o8 = torch.zeros(2, M, N, dtype=torch.uint8, device=DEV)
     rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8, w8=W8, out8=o8)
     close(oh.float(), F.gelu(a.double() @ w.double().t() + b.double()).float(), 2e-5)
-    want = pack.planes8(oh)
-    assert (o8.int() - want.int()).abs().max() <= 1 and (o8 != want).float().mean() < 1e-3
+    _same_rows(o8, pack.planes8(oh, pack.ORDER_GEMM))    # the epilogue's rows == the packer's on the planes it wrote
+    _check_x6(o8, oh, M, N, pack.ORDER_GEMM)
     first = (oh.hi.clone(), oh.lo.clone())
     for _ in range(5):
         rt3.gemm(A, W, M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8, w8=W8, out8=o8)
@@ -1059,13 +1059,35 @@ def _unkt8(t, rows, K):
     return t.reshape(K // 64, rows, 64).permute(1, 0, 2).reshape(rows, K)
 
 
+def _same_rows(a, b):
+    """Two plane pairs of x6 rows agree on every byte that means something (24 code bytes + the scale byte per 32-byte half)."""
+    a, b = a.reshape(-1, 32), b.reshape(-1, 32)
+    assert torch.equal(a[:, :25], b[:, :25])
+
+
+def _check_x6(p8, t, rows, K, order, kt=False):
+    """What the planes stand for: plane 0 ~ hi within the e3m2 grid of its half (2 mantissa bits below the half's largest
+    value: |err| <= max / 16 once saturation of (30, 32) is counted), plane 1 ~ lo on a grid 2^-10 finer."""
+    from vdn import pack
+    hi, lo = t.hi.float(), t.lo.float()
+    d0, d1 = pack.decode6(p8[0], rows, K, order, kt), pack.decode6(p8[1], rows, K, order, kt)
+    cols = pack.x6_columns(order).to(hi.device)
+    for h in range(2):
+        idx = (torch.arange(K // 64, device=hi.device)[:, None] * 64 + cols[h][None, :])          # [slabs, 32]
+        mx = hi[:, idx].abs().amax(dim=-1, keepdim=True)                                           # [rows, slabs, 1]
+        assert ((d0[:, idx] - hi[:, idx]).abs() <= mx / 8 + 1e-30).all()
+        assert ((d0[:, idx] - hi[:, idx]).abs() <= 0.13 * hi[:, idx].abs() + mx / 256).all()       # 2 mantissa bits, subnormal step max / 256
+        assert ((d1[:, idx] - lo[:, idx]).abs() <= 0.13 * lo[:, idx].abs() + mx / 1024 / 256 + 1e-30).all()
+
+
 @pytest.mark.parametrize("bm", [0, 192, 256])
 @pytest.mark.parametrize("M,N,K", [(2740, 1024, 1024), (1370 * 2 + 77, 3072, 384), (2048, 512, 4096), (4100, 1024, 64)])
 def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
-    """The 8-bit cross-term kernel on K-tile-major operand planes ([K/32][rows][32] halves, [K/64][rows][64] bytes): weights
-    through vdn_pack_x8, activations permuted on the host; bitwise equal to the same kernel on row-major planes (the
-    arithmetic does not depend on the layout), fp64-close; GELU output written K-tile-major with its 8-bit planes and no
-    fp16 lo plane, as fc1 hands it to fc2."""
+    """The cross-term kernel on K-tile-major operand planes ([K/32][rows][32] halves, [K/64][rows][64] bytes of 6-bit rows):
+    weights through vdn_pack_x8, activations permuted on the host; bitwise equal to the same kernel on row-major planes (the
+    arithmetic does not depend on the layout), fp64-close; the same product from planes in the other two stream orders
+    (A and W packed alike); GELU output written K-tile-major with its planes of 6-bit rows and no fp16 lo plane, as fc1
+    hands it to fc2, and fc2 consuming them."""
     from vdn import pack, _abi
     from vdn.runtime import HL
     tune(force_bm=bm)   # 0: the launch picks its M tile (192 or 256 rows); else pinned — the results must not depend on it
@@ -1086,21 +1108,33 @@ def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
     rt3.gemm(Ak, HL(X.hi), M, N, K, out=xk, bias=b.to(DEV), gamma=g.to(DEV), res1=xk, a8=A8k, w8=X.p8, a_kt=True, w_kt=True)
     assert torch.equal(xk, xr)
     close(xk, ref, 2e-5)
+    _check_x6(A8, A, M, K, pack.ORDER_NATURAL)
+    for order in (pack.ORDER_GEMM, pack.ORDER_ATTN):   # any order, as long as both operands use it
+        xo = x.clone().to(DEV)
+        rt3.gemm(Ak, HL(X.hi), M, N, K, out=xo, bias=b.to(DEV), gamma=g.to(DEV), res1=xo, a8=pack.planes8(A, order, kt=True),
+                 w8=pack.X8(W, order).p8, a_kt=True, w_kt=True)
+        close(xo, ref, 2e-5)
     if N % 64 == 0:
         oh = HL(torch.zeros(M, N, dtype=torch.float16, device=DEV))
         o8 = torch.zeros(2, M, N, dtype=torch.uint8, device=DEV)
         rt3.gemm(Ak, HL(X.hi), M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8k, w8=X.p8, out8=o8, a_kt=True, w_kt=True, out_kt=True)
         refg = F.gelu(a.double() @ w.double().t() + b.double()).float()
         hi = _unkt16(oh.hi, M, N).float()
-        lo = _unkt8(o8[1], M, N).view(torch.float8_e5m2).float() / 1024.0
-        close(hi + lo, refg, 3e-5)                                   # hi + the e5m2 remainder: 2^-14 relative
-        close(_unkt8(o8[0], M, N).view(torch.float8_e5m2).float(), refg, 0.08)   # e5m2(value): 2 mantissa bits
+        close(hi + pack.decode6(o8[1], M, N, pack.ORDER_GEMM, kt=True), refg, 3e-5)   # hi + the 6-bit remainder: 2^-14 relative
+        close(pack.decode6(o8[0], M, N, pack.ORDER_GEMM, kt=True), refg, 0.08)        # 2 mantissa bits
+        # ... and the next GEMM consuming them (weights packed in the epilogue's order): fc1 -> fc2
+        w2 = rnd(512, N, seed=995, scale=1 / math.sqrt(N))
+        X2 = pack.X8(pack.linear(w2.to(DEV), rt3.prec), pack.ORDER_GEMM)
+        y = torch.zeros(M, 512, device=DEV)
+        rt3.gemm(oh, HL(X2.hi), M, 512, N, out=y, a8=o8, w8=X2.p8, a_kt=True, w_kt=True)
+        close(y, (refg.double() @ w2.double().t()).float(), 6e-5)   # the input planes (2^-14) and the product's own cross terms
 
 
 @pytest.mark.parametrize("rows,C", [(77, 384), (1370, 1024), (300, 64)])
 def test_layernorm_8bit_planes_and_k_tile_major(rt3, rows, C):
-    """vdn_layernorm(out8, kt): the hi plane + e5m2 (value, remainder 2^10) planes of the 8-bit GEMM's A operand, row-major
-    and K-tile-major, against the plain split-plane output of the same launch."""
+    """vdn_layernorm(out8, kt): the hi plane + the planes of 6-bit rows of the cross-term GEMM's A operand, row-major and
+    K-tile-major, against the plain split-plane output of the same launch pushed through vdn_pack_x8."""
+    from vdn import pack
     from vdn.runtime import HL
     x = rnd(rows, C, seed=995).to(DEV)
     w, b = rnd(C, seed=996).to(DEV), rnd(C, seed=997).to(DEV)
@@ -1111,18 +1145,14 @@ def test_layernorm_8bit_planes_and_k_tile_major(rt3, rows, C):
         o8 = torch.zeros(2, rows, C, dtype=torch.uint8, device=DEV)
         rt3.layernorm(x, rows, C, w, b, 1e-6, out_h=oh, out8=o8, kt=kt)
         hi = _unkt16(oh.hi, rows, C) if kt else oh.hi
-        p0 = _unkt8(o8[0], rows, C) if kt else o8[0]
-        p1 = _unkt8(o8[1], rows, C) if kt else o8[1]
         assert torch.equal(hi, ref.hi)
-        want0 = ref.float().to(torch.float8_e5m2).view(torch.uint8)
-        want1 = (ref.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)
-        assert (p0.int() - want0.int()).abs().max() <= 1 and (p0 != want0).float().mean() < 2e-3   # ties of the fp32 value vs hi + lo
-        assert torch.equal(p1, want1)
+        _same_rows(o8, pack.planes8(ref, pack.ORDER_NATURAL, kt=kt))
+        _check_x6(o8, ref, rows, C, pack.ORDER_NATURAL, kt=kt)
 
 
 def test_flash_attention_8bit_output_planes_k_tile_major(rt3):
     """vdn_flash_attn(out8, out_kt): the attention output as the proj GEMM's K-tile-major A planes == the row-major planes
-    of the same launch, permuted; remainder plane = e5m2(lo 2^10)."""
+    of the same launch, permuted; the planes of 6-bit rows == vdn_pack_x8 (attention order) on the split output."""
     from vdn import pack, _abi
     from vdn.runtime import HL
     B, Hh, T = 2, 3, 150
@@ -1140,7 +1170,9 @@ def test_flash_attention_8bit_output_planes_k_tile_major(rt3):
     o8 = torch.zeros(2, B * T, C, dtype=torch.uint8, device=DEV)
     rt3.flash_attn(q, k, vt, oh, B, Hh, T, tp, T, tp, 0.125, q8=q8, k8=k8, out8=o8, out_kt=True)
     assert torch.equal(_unkt16(oh.hi, B * T, C), ref.hi)
-    assert torch.equal(_unkt8(o8[1], B * T, C), (ref.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8))
-    want0 = ref.float().to(torch.float8_e5m2).view(torch.uint8)
-    p0 = _unkt8(o8[0], B * T, C)
-    assert (p0.int() - want0.int()).abs().max() <= 1 and (p0 != want0).float().mean() < 2e-3
+    _same_rows(o8, pack.planes8(ref, pack.ORDER_ATTN, kt=True))
+    _check_x6(o8, ref, B * T, C, pack.ORDER_ATTN, kt=True)
+    o8r = torch.zeros(2, B * T, C, dtype=torch.uint8, device=DEV)    # row-major planes
+    ohr = HL(torch.zeros(B * T, C, dtype=torch.float16, device=DEV))
+    rt3.flash_attn(q, k, vt, ohr, B, Hh, T, tp, T, tp, 0.125, q8=q8, k8=k8, out8=o8r)
+    _same_rows(o8r, pack.planes8(ref, pack.ORDER_ATTN))

@@ -45,8 +45,7 @@ for bm in (256, 192):
     for (M, N, K) in ((10960, 4096, 1024), (5480, 1024, 4096), (10960, 1024, 64), (4100, 3072, 192)):
         a = rt.to_half(torch.randn(M, K, device="cuda"))
         w = pack.linear(torch.randn(N, K, device="cuda") / math.sqrt(K), rt.prec)
-        a8 = pack.planes8(a)
-        ak, a8k = HL(kt16(a.hi, M, K)), torch.stack([kt8(a8[0], M, K), kt8(a8[1], M, K)]).contiguous()
+        ak, a8k = HL(kt16(a.hi, M, K)), pack.planes8(a, kt=True)
         x8 = pack.X8(w)
         bias = torch.randn(N, device="cuda")
         kt = dict(a8=a8k, w8=x8.p8, a_kt=True, w_kt=True)

@@ -28,8 +28,7 @@ cases = []
 for name, N, K, kind in (("qkv", 3072, 1024, "heads"), ("proj", 1024, 1024, "res"), ("fc1", 4096, 1024, "gelu"), ("fc2", 1024, 4096, "res")):
     a = rt.to_half(torch.randn(M, K, device="cuda"))
     w = pack.linear(torch.randn(N, K, device="cuda") / math.sqrt(K), rt.prec)
-    a8 = pack.planes8(a)
-    ak, a8k = HL(kt16(a.hi, M, K)), torch.stack([kt8(a8[0], M, K), kt8(a8[1], M, K)]).contiguous()
+    ak, a8k = HL(kt16(a.hi, M, K)), pack.planes8(a, kt=True)
     x8 = pack.X8(w)
     bias = torch.randn(N, device="cuda")
     kw3, kw8 = {}, dict(a8=a8k, w8=x8.p8, a_kt=True, w_kt=True)

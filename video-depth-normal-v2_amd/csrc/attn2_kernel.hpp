@@ -367,6 +367,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int b = bh / H, hd = bh - b * H;
     const size_t row = (size_t)b * nq + q;
     const size_t oo = (row * H + hd) * 64;
+    [[maybe_unused]] f16x32 hv6, lv6;   // out8: the lane's 32 channels (stream position 16 db + 4 g + e) = one half of the head's slab
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -387,13 +388,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const size_t od = out_kt ? ((size_t)(2 * hd + db) * out_rows + row) * 32 + 8 * g + 4 * h : oo + c;
         *(typename HT::V4*)(out + od) = v;
         if (outl) *(typename HT::V4*)(outl + od) = vl;
-        if (out8) {  // e5m2(o) and e5m2(remainder 2^10) (vdn_gemm_desc.A8)
-          uint8_t* d8 = out8 + (out_kt ? ((size_t)hd * out_rows + row) * 64 + c : oo + c);
-          const float k = VDN_LO8_SCALE;
-          *(uint32_t*)d8 = pk4_bf8(f[0], f[1], f[2], f[3]);
-          *(uint32_t*)(d8 + (size_t)out_rows * H * 64) = pk4_bf8(k * (float)vl[0], k * (float)vl[1], k * (float)vl[2], k * (float)vl[3]);
+        if constexpr (std::is_same_v<T, _Float16>) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hv6[16 * db + 4 * g + e] = v[e]; lv6[16 * db + 4 * g + e] = vl[e]; }
         }
       }
+    if constexpr (std::is_same_v<T, _Float16>) {
+      if (out8) {  // 6-bit rows of the projection's A operand (common.hpp x6 rows, order 2): hi plane, then the remainder plane
+        const int sb = x6_scale_byte(hv6);
+        uint8_t* d8 = out8 + (out_kt ? ((size_t)hd * out_rows + row) * 64 : oo) + 32 * h;
+        x6_store_half(d8, hv6, sb);
+        x6_store_half(d8 + (size_t)out_rows * H * 64, lv6, sb - 10);
+      }
+    }
   }
 #undef A2_IC
 #undef A2_PIN

@@ -202,6 +202,47 @@ __device__ __forceinline__ uint32_t pk4_bf8(float a, float b, float c, float d) 
 constexpr float VDN_LO8_SCALE = 1024.0f;  // 2^10; E8M0 byte 127 - 10 on the other side
 constexpr int VDN_LO8_E8M0 = 117;
 
+// ---- 6-bit block-scaled operand rows of the cross-term GEMM (include/vdn.h: vdn_gemm_desc.A8 / W8 / out8, "x6 rows").
+// Per row and 64 of K one 64-byte row-slab = two HALVES of 32 bytes, one per K half of the 32x32x64 MFMA:
+//   [24 B: 32 e3m2 codes (sign, 3 exponent bits bias 3, 2 mantissa bits; 6-bit fields, little-endian bit stream)]
+//   [ 1 B: E8M0 scale byte s of the half: value = code * 2^(s - 127)] [7 B unused]
+// so that the two 16-byte LDS reads of a lane ARE its MFMA operand (registers 0..5) and its scale operand (register 6).
+// Scale of a half: 2^(floor(log2 max|hi|) - 4), the largest hi lands in [16, 32) (e3m2 tops out at 28: the few values
+// in (30, 32) saturate, 12.5 % at worst, the rounding error of the format). The remainder plane of the same half uses
+// that scale - 10: |lo| < ulp(hi) <= 2^-10 of the largest hi, so it lands below 16.
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ int x6_scale_byte(const f16x32& hi) {
+  typedef unsigned short u16x32 __attribute__((ext_vector_type(32)));
+  typedef unsigned short u16x16 __attribute__((ext_vector_type(16)));
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x32 b = __builtin_bit_cast(u16x32, hi) & (unsigned short)0x7FFF;   // magnitudes: fp16 patterns order like integers
+  const u16x16 m16 = __builtin_elementwise_max(b.lo, b.hi);
+  const u16x8 m8 = __builtin_elementwise_max(m16.lo, m16.hi);
+  const u16x4 m4 = __builtin_elementwise_max(m8.lo, m8.hi);
+  const u16x2 m2 = __builtin_elementwise_max(m4.lo, m4.hi);
+  const unsigned m = m2[0] > m2[1] ? m2[0] : m2[1];
+  return (int)(m >> 10) + 108;   // fp16 exponent field e: 2^(e - 15 - 4) -> E8M0 byte 127 + e - 19
+}
+// one half (32 fp16 values in stream order) -> 32 bytes at dst (16-byte aligned)
+__device__ __forceinline__ void x6_store_half(uint8_t* dst, const f16x32& v, int scale_byte) {
+  const u32x6 c = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, __builtin_bit_cast(float, (unsigned)scale_byte << 23));
+  *(u32x4*)dst = u32x4{c[0], c[1], c[2], c[3]};
+  *(u32x4*)(dst + 16) = u32x4{c[4], c[5], (unsigned)scale_byte, 0u};
+}
+// Column of a 64-wide K slab that sits at stream position p (0..31) of half h, by the ORDER the producer of the activation
+// planes writes (the weight planes of the consuming GEMM are packed in the same order, vdn_pack_x8):
+//   0 natural        col = 32 h + p                                  vdn_layernorm, vdn_pack_x8 on activations
+//   1 GEMM epilogue  col = 32 (p >> 4) + 16 ((p >> 3) & 1) + 8 h + (p & 7)     the bias + GELU flavour of the 8-bit kernel
+//   2 attention      col = 32 (p >> 4) + 8 ((p >> 2) & 3) + 4 h + (p & 3)      vdn_flash_attn
+__host__ __device__ __forceinline__ int x6_col(int order, int h, int p) {
+  return order == 1 ? 32 * (p >> 4) + 16 * ((p >> 3) & 1) + 8 * h + (p & 7)
+       : order == 2 ? 32 * (p >> 4) + 8 * ((p >> 2) & 3) + 4 * h + (p & 3)
+                    : 32 * h + p;
+}
+
 // store 1 value: hi-only (round to nearest) or split planes
 template <typename T>
 __device__ __forceinline__ void store_half(T* hi, T* lo, size_t i, float v) {

@@ -75,7 +75,8 @@ extern "C" int vdn_gemm(const vdn_gemm_desc* dp, vdn_stream stream) {
   if ((d.res1 && (d.ldr1 & 3)) || (d.res2 && (d.ldr2 & 3))) return VDN_EALIGN;
   if (((uintptr_t)d.A8 | (uintptr_t)d.W8 | (uintptr_t)d.out8) & 15) return VDN_EALIGN;
   if ((d.A8 || d.W8) && (d.dt != VDN_F16 || d.a_mode != VDN_A_PLAIN || (d.K & 63) || (d.lda != d.K && !d.a_kt))) return VDN_EINVAL;
-  if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || (d.ldc & 63))) return VDN_EINVAL;
+  if (d.out8 && (d.dt != VDN_F16 || d.store != VDN_ST_PLAIN || d.out_dt != VDN_F16 || d.act != VDN_ACT_GELU || d.N != d.ldc || (d.N & 63) || !d.A8 || !d.W8))
+    return VDN_EINVAL;
   if ((d.a_kt || d.w_kt || d.out_kt || d.x8_terms) && (!d.A8 || !d.W8)) return VDN_EINVAL;
   // the 8-bit kernel addresses a lane's rows with 32-bit byte offsets inside a plane (row-major planes: rows * ld elements)
   if (d.A8 && d.W8 && ((!d.a_kt && (long)d.M * d.lda >= (1L << 31)) || (!d.w_kt && (long)d.N * d.ldb >= (1L << 31)) || d.M >= (1 << 25) || d.N >= (1 << 25)))

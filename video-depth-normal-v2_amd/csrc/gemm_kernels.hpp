@@ -118,12 +118,6 @@ __device__ __forceinline__ void emit4(const vdn_gemm_desc& p, int m, int n, f32x
     }
     *(typename H::V4*)((T*)p.out + o) = h;
     if (p.out_lo) *(typename H::V4*)((T*)p.out_lo + o) = l;
-    if (p.out8) {  // 8-bit planes for the consuming GEMM's cross terms: e5m2(v) [M, ldc], then the remainder plane
-      uint8_t* d8 = (uint8_t*)p.out8 + (p.out_kt ? ((size_t)(n >> 6) * p.M + m) * 64 + (n & 63) : o);
-      const float k = VDN_LO8_SCALE;
-      *(uint32_t*)d8 = pk4_bf8(a[0], a[1], a[2], a[3]);
-      *(uint32_t*)(d8 + (size_t)p.M * p.ldc) = pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]);
-    }
     return;
   } else if constexpr (STORE == VDN_STX_HALF || STORE == VDN_STX_RESHALF1 || STORE == VDN_STX_RESHALF2) {
     // [bias] [relu] [+ split-half residual(s)] -> split half planes, plain rows (the DPT head's convolutions)
@@ -412,15 +406,6 @@ __device__ __forceinline__ void emit8(const vdn_gemm_desc& p, int m, int n, f32x
     const size_t o = p.out_kt ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ldc + n;
     *(V8*)((T*)p.out + o) = h;
     if (p.out_lo) *(V8*)((T*)p.out_lo + o) = l;
-    if constexpr (STORE == VDN_STX_FC1) {
-      if (p.out8) {  // e5m2(v) and e5m2(remainder 2^10): the A8 planes of the consuming GEMM
-        uint8_t* d8 = (uint8_t*)p.out8 + (p.out_kt ? ((size_t)(n >> 6) * p.M + m) * 64 + (n & 63) : o);
-        const float k = VDN_LO8_SCALE;
-        *(u32x2*)d8 = u32x2{pk4_bf8(a[0], a[1], a[2], a[3]), pk4_bf8(a[4], a[5], a[6], a[7])};
-        *(u32x2*)(d8 + (size_t)p.M * p.ldc) = u32x2{pk4_bf8(k * (float)l[0], k * (float)l[1], k * (float)l[2], k * (float)l[3]),
-                                                    pk4_bf8(k * (float)l[4], k * (float)l[5], k * (float)l[6], k * (float)l[7])};
-      }
-    }
   }
 }
 

@@ -1,19 +1,23 @@
-// gemm_x8_kernel: out = epilogue(A W^T) with the split-precision cross terms on the block-scaled 8-bit MFMA.
+// gemm_x8_kernel: out = epilogue(A W^T) with the split-precision cross terms on the block-scaled MFMA.
 //
-//   A W^T = A_hi W_hi^T                      fp16 v_mfma_f32_32x32x16_f16            (4 per 32x32 block and 64-deep slab)
-//         + 2^-10 (A8 W_lo8^T + A_lo8 W8^T)  e5m2 v_mfma_scale_f32_32x32x64_f8f6f4   (2 per block and slab, 2.3x the fp16 rate)
+//   A W^T = A_hi W_hi^T                  fp16 v_mfma_f32_32x32x16_f16            (4 per 32x32 block and 64-deep slab)
+//         + A_hi6 W_lo6^T + A_lo6 W_hi6^T  e3m2 v_mfma_scale_f32_32x32x64_f8f6f4   (2 per block and slab, 4.2x the fp16 rate)
 //
-// X8 = e5m2(X), X_lo8 = e5m2((X - X_hi) 2^10) come as two byte planes per operand, shaped like the fp16 operand
-// (u8 [2, rows, K]; include/vdn.h A8 / W8). A cross term is 2^-11 of the product and e5m2 keeps 3 significant bits of it:
-// 2^-14 per term, against 2^-22 for the third fp16 product it replaces and 2^-11 for dropping it. Bytes per
-// element are unchanged (2 + 1 + 1); matrix-pipe cycles per 32 x 32 block and 64 of K drop from 384 to ~240.
+// X_hi6 / X_lo6 are planes of "x6 rows" (common.hpp; include/vdn.h A8 / W8): per row and 64 of K two 32-byte halves of 32
+// e3m2 codes + the E8M0 scale byte of the half (scale of the remainder plane = scale of the hi plane - 10). A cross term is
+// 2^-11 of the product and e3m2 keeps 3 significant bits of it: 2^-14 per term, against 2^-22 for the third fp16 product it
+// replaces and 2^-11 for dropping it. Bytes per element stay 2 + 1 + 1 (the two 16-byte LDS reads of a lane
+// are its MFMA operand and its scale operand); matrix-pipe cycles per 32 x 32 block and 64 of K drop from 384 (three fp16
+// products) to ~190. Round 3 first shipped these planes as e5m2 bytes (2.3x rate, ~240 cycles); the 6-bit rows took the
+// block of four encoder linears from 640 to 615 us (not further: in the two cross-term phases the 48 KiB of fragment reads
+// per wave group, 384 LDS cycles, now outlast the 240 matrix-pipe cycles; profiles/r03_x6.md).
 //
 // 256 x 256 tile, 8 waves (2 x 4; a wave owns 128 A rows x 64 W rows = 4 x 2 blocks of 32 x 32, 128 accumulator
 // registers), weights as the MFMA's first operand, so a lane holds one activation row (lane & 31) and runs of 4
 // consecutive output columns: the fp32 epilogues of gemm_kernels.hpp (emit4) apply unchanged.
 //
 // Structure = the ping-pong of gemm_x3_p8_kernel on 64-deep slabs. A slab is 4 UNITS of 32 KiB (256 rows x 64 B of A and
-// of W each): fp16 k 0..31, fp16 k 32..63, [A_lo8 | W8], [A8 | W_lo8]; unit n = 4 slab + phase is read in global phase n
+// of W each): fp16 k 0..31, fp16 k 32..63, [A_lo6 | W_hi6], [A_hi6 | W_lo6]; unit n = 4 slab + phase is read in global phase n
 // and lives in ring slot n mod NSLOT. The two wave groups (waves 0-3 = A rows 0..127, waves 4-7 = rows 128..255; wave w
 // and w + 4 share a SIMD) run ONE BARRIER APART: between two barriers one group issues 512 matrix-pipe cycles (16 fp16 or
 // 8 scaled MFMAs) on fragments it already holds while the other reads its next 12 fragments and issues its 4 pieces
@@ -40,15 +44,14 @@ constexpr int X8_WH = 256 * 64;   // bytes of the W half of a unit: 256 rows x 6
 #define VDN_X8_NSLOT 5
 #endif
 #ifndef VDN_X8_ABL
-#define VDN_X8_ABL 0   // timing-only builds (tools/build_variant.sh): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads, 8 = clock stamps,
-#endif                 // 16 = cross terms in a 6-bit format from 24-KiB units (what e3m2 planes would cost; results meaningless)
+#define VDN_X8_ABL 0   // timing-only builds (tools/build_variant.sh): 1 = no MFMAs, 2 = no DMA, 4 = no fragment reads, 8 = clock stamps
+#endif
 constexpr int X8_NSLOT = VDN_X8_NSLOT;
 constexpr int x8_unit(int bm) { return bm * 64 + X8_WH; }  // 32 KiB (BM 256) or 28 KiB (BM 192)
 constexpr int X8_L = X8_NSLOT - 1;  // issue lead in phases
 // DMA instructions one wave issues for the unit of phase ph (`four`: the wave moves 2 A pieces, else 1)
 constexpr int x8_pc(int ph, bool four) {
   const int a = four ? 2 : 1, w = 2;
-  if ((VDN_X8_ABL & 16) && ph >= 2) return a + 1;
   return a + w;
 }
 // ... for the k newest units, the newest being the unit of phase `newest`
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   }
   const char* Ah = (const char*)p.A;               // fp16 plane
   const char* Wh = (const char*)p.W;
-  const char* A8v = (const char*)p.A8;             // e5m2(A); the remainder plane follows at + M K bytes
-  const char* W8v = (const char*)p.W8;             // e5m2(W); remainder plane at + N ldb bytes
+  const char* A8v = (const char*)p.A8;             // x6 rows of A_hi; the remainder plane follows at + M K bytes
+  const char* W8v = (const char*)p.W8;             // x6 rows of W_hi; remainder plane at + N ldb bytes
   const size_t a8l = (size_t)p.M * p.K, w8l = (size_t)p.N * p.ldb;
   // issue this wave's pieces of unit (slab, ph) into ring slot `slot` (ph is a compile-time constant)
   auto issue = [&](int slab, auto phc, int slot) {
@@ -130,14 +133,13 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
     if constexpr (ph < 2) {
       ba = Ah + (size_t)(2 * slab + ph) * a_kts;
       bw = Wh + (size_t)(2 * slab + ph) * w_kts;
-    } else {  // phase 2: A_lo8 with W8; phase 3: A8 with W_lo8
+    } else {  // phase 2: A_lo6 with W_hi6; phase 3: A_hi6 with W_lo6
       ba = A8v + (ph == 2 ? a8l : 0) + (size_t)slab * a8_kts;
       bw = W8v + (ph == 2 ? 0 : w8l) + (size_t)slab * w8_kts;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (AP == 16 || wave + 8 * i < AP) X8_GLDS(ba + (ph < 2 ? ah_o[i] : a8_o[i]), ua + (wave + 8 * i) * 1024);
-      if constexpr ((VDN_X8_ABL & 16) && ph >= 2) { if (i == 1) continue; }  // timing model of 6-bit planes: 3 pieces per wave
       X8_GLDS(bw + (ph < 2 ? wh_o[i] : w8_o[i]), uw + (wave + 8 * i) * 1024);
     }
   };
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   } while (0)
 
   // ---- fragment addresses inside a unit (64-byte rows): 16-byte chunk c of row `row` sits at c ^ ((-(row >> 2)) & 3).
-  // fp16 32x32x16 operand, k-step ks (0, 1) of the unit: chunk 2 ks + h. e5m2 32x32x64 operand: bytes 32 h .. 32 h + 31 =
+  // fp16 32x32x16 operand, k-step ks (0, 1) of the unit: chunk 2 ks + h. e3m2 32x32x64 operand: half h of the row-slab =
   // chunks 2 h, 2 h + 1.
   // The swizzle term depends on (row >> 2) & 3 = (r >> 2) & 3 only (a wave's blocks start at multiples of 32 rows), so
   // block i / j of an operand is the block-0 address plus an instruction immediate.
@@ -162,10 +164,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
   const int a8_off0 = (wm * (X8_BM / 2) + r) * 64 + (((2 * h) ^ swz) << 4);  // byte operand: chunk 2 h; chunk 2 h + 1 = bit 4 flipped
   const int w8_off0 = X8_H + (wn * 64 + r) * 64 + (((2 * h) ^ swz) << 4);
   auto rd8 = [&](const char* u, int off) {
-    u32x4 a0 = *(const u32x4*)(u + off), a1;
-    if constexpr (VDN_X8_ABL & 16) { const u32x2 t = *(const u32x2*)(u + (off ^ 16)); a1 = u32x4{t[0], t[1], 0u, 0u}; }
-    else a1 = *(const u32x4*)(u + (off ^ 16));
-    i32x8 v;
+    const u32x4 a0 = *(const u32x4*)(u + off), a1 = *(const u32x4*)(u + (off ^ 16));
+    i32x8 v;   // registers 0..5: the 32 codes; register 6: the scale byte; 7: unused
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = (int)a0[e]; v[4 + e] = (int)a1[e]; }
     return v;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- phase bodies: the fragment READS of a phase and its MFMAs
-  const int sc_alo = p.x8_terms == 1 ? 0 : VDN_LO8_E8M0, sc_wlo = p.x8_terms == 2 ? 0 : VDN_LO8_E8M0;
+  const int m_alo = p.x8_terms == 1 ? 0 : -1, m_wlo = p.x8_terms == 2 ? 0 : -1;  // 0: that cross term is dropped (scale 2^-127)
   V8 hw[2][2] = {}, ha[2][NI] = {};  // fp16 phases: [k-step][block]
   i32x8 cw[2] = {}, ca[NI] = {};     // byte phases
   auto reads = [&](auto phc, int slot) {
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       for (int i = 0; i < NI; ++i) ca[i] = rd8(u + i * 2048, a8_off0);
     }
   };
-  // fp16 phases: A_hi W_hi^T over a 32-deep unit (2 k-steps x 8 blocks). Byte phases: one cross term over the slab,
-  // phase 2 = W8 A_lo8^T, phase 3 = W_lo8 A8^T (the remainder planes carry 2^10; the E8M0 scale of that operand removes it).
+  // fp16 phases: A_hi W_hi^T over a 32-deep unit (2 k-steps x 8 blocks). 6-bit phases: one cross term over the slab,
+  // phase 2 = W_hi6 A_lo6^T, phase 3 = W_lo6 A_hi6^T.
   auto mfmas = [&](auto phc) {
     constexpr int ph = decltype(phc)::value;
     if constexpr (VDN_X8_ABL & 1) {  // keep the fragments live
@@ -229,11 +229,12 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          // sc_alo / sc_wlo: the E8M0 scale of the remainder plane (2^-10), or 0 = 2^-127 when this launch drops that cross
-          // term (include/vdn.h x8_terms): the product then vanishes in the fp32 accumulator, no branch in the loop
-          constexpr int FM = (VDN_X8_ABL & 16) ? 3 : 1;   // 1 = e5m2; 3 = e3m2 (timing model of 6-bit planes)
-          if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], FM, FM, 0, 127, 0, sc_alo);
-          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], FM, FM, 0, sc_wlo, 0, 127);
+          // operands = registers 0..5 (32 e3m2 codes), E8M0 scale = byte 0 of register 6 (this lane's row and K half); a
+          // launch that drops a cross term (include/vdn.h x8_terms) zeroes that plane's scale byte: 2^-127, the product
+          // vanishes in the fp32 accumulator, no branch in the loop
+          const int sw = cw[j][6], sa = ca[i][6];
+          if constexpr (ph == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 3, 3, 0, sw, 0, sa & m_alo);
+          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cw[j], ca[i], acc[i][j], 3, 3, 0, sw & m_wlo, 0, sa);
           if (j == 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -350,16 +351,57 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
           const int n = nw + 32 * j + 16 * u + 8 * h + 4 * q;
           bias8[j][u][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : z4;
         }
+    if (STORE == VDN_STX_FC1 && p.out8) {
+      // bias + GELU -> the fp16 hi plane and the two planes of 6-bit rows of the consuming GEMM's A operand. The lane's 32
+      // values of block row i (stream position 16 j + 8 u + e = column 32 j + 16 u + 8 h + e of the wave's 64-wide slab) are
+      // one HALF of the slab: its scale comes from the lane's own values, no exchange (common.hpp x6 rows, order 1).
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NI; ++i) {
+        const int m = mw + 32 * i + r;
+        f16x32 hv, lv;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const f32x4 a0 = {acc[i][j][8 * u], acc[i][j][8 * u + 1], acc[i][j][8 * u + 2], acc[i][j][8 * u + 3]};
-          const f32x4 a1 = {acc[i][j][8 * u + 4], acc[i][j][8 * u + 5], acc[i][j][8 * u + 6], acc[i][j][8 * u + 7]};
-          emit8<VDN_F16, STORE>(p, mw + 32 * i + r, nw + 32 * j + 16 * u + 8 * h, a0, a1, bias8[j][u][0], bias8[j][u][1]);
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 g0 = gelu4(f32x4{acc[i][j][8 * u], acc[i][j][8 * u + 1], acc[i][j][8 * u + 2], acc[i][j][8 * u + 3]} + bias8[j][u][0]);
+            const f32x4 g1 = gelu4(f32x4{acc[i][j][8 * u + 4], acc[i][j][8 * u + 5], acc[i][j][8 * u + 6], acc[i][j][8 * u + 7]} + bias8[j][u][1]);
+            V8 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              _Float16 h0, h1, l0, l1;
+              split2_rtz(g0[e], g0[e + 1], h0, h1, l0, l1);
+              hh[e] = h0; hh[e + 1] = h1; ll[e] = l0; ll[e + 1] = l1;
+              split2_rtz(g1[e], g1[e + 1], h0, h1, l0, l1);
+              hh[4 + e] = h0; hh[5 + e] = h1; ll[4 + e] = l0; ll[5 + e] = l1;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hv[16 * j + 8 * u + e] = hh[e]; lv[16 * j + 8 * u + e] = ll[e]; }
+            const int n = nw + 32 * j + 16 * u + 8 * h;
+            if (m < p.M && n < p.N) {
+              const size_t o = p.out_kt ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ldc + n;
+              *(V8*)((_Float16*)p.out + o) = hh;
+              if (p.out_lo) *(V8*)((_Float16*)p.out_lo + o) = ll;
+            }
+          }
+        if (m < p.M && nw < p.N) {
+          const int sb = x6_scale_byte(hv);
+          uint8_t* d8 = (uint8_t*)p.out8 + (p.out_kt ? ((size_t)(nw >> 6) * p.M + m) * 64 : (size_t)m * p.ldc + nw) + 32 * h;
+          x6_store_half(d8, hv, sb);
+          x6_store_half(d8 + (size_t)p.M * p.ldc, lv, sb - 10);
         }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 a0 = {acc[i][j][8 * u], acc[i][j][8 * u + 1], acc[i][j][8 * u + 2], acc[i][j][8 * u + 3]};
+            const f32x4 a1 = {acc[i][j][8 * u + 4], acc[i][j][8 * u + 5], acc[i][j][8 * u + 6], acc[i][j][8 * u + 7]};
+            emit8<VDN_F16, STORE>(p, mw + 32 * i + r, nw + 32 * j + 16 * u + 8 * h, a0, a1, bias8[j][u][0], bias8[j][u][1]);
+          }
+    }
   } else if constexpr (STORE == VDN_STX_RES) {  // (acc + bias) * gamma + f32 residual -> f32 rows (in place)
     f32x4 bias4[2][4], gam4[2][4];
 #pragma unroll
@@ -440,6 +482,7 @@ static int x8_launch(const vdn_gemm_desc& d, hipStream_t s) {
   int fl = epi_flavour(d);
   // plane-output flavours store 8 columns (16 bytes) per lane: column counts and strides must keep that aligned
   const bool a8 = !(d.N & 7) && !(d.ldc & 7) && !((uintptr_t)d.out & 15) && !((uintptr_t)d.out_lo & 15) && !((uintptr_t)d.out8 & 7);
+  if (d.out8 && !(a8 && fl == VDN_STX_FC1 && !(d.N & 63))) return VDN_EUNSUPPORTED;  // 6-bit output rows: the paired bias + GELU epilogue only
   if (!a8 && fl != VDN_STX_RES && fl != VDN_STX_HEADS) fl = d.store;
   if (fl == VDN_STX_RESHALF1 || fl == VDN_STX_RESHALF2) fl = d.store;
   switch (fl) {

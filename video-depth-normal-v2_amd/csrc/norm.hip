@@ -25,6 +25,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
   using XV = typename Vec4<XT>::V;
   const int lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
+  __shared__ __attribute__((aligned(16))) _Float16 stage_all[DT == VDN_F16 ? 4 * 2 * NV * 256 : 8];   // out8: per wave, hi and remainder of a row
+  _Float16* const stage = stage_all + (DT == VDN_F16 ? (threadIdx.x >> 6) * 2 * NV * 256 : 0);
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   f32x4 wv[NV], bv[NV];
 #pragma unroll
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
                 hv[e] = h0; hv[e + 1] = h1; lv[e] = l0; lv[e + 1] = l1;
               }
               if (out_l) *(typename Half<DT>::V4*)(out_l + oh) = lv;
-              if (out8) {  // e5m2(y) and e5m2(remainder 2^10) (vdn_gemm_desc.A8)
-                uint8_t* d8 = out8 + (kt ? ((size_t)(c >> 6) * rows + orow) * 64 + (c & 63) : orow * C + c);
-                const float k = VDN_LO8_SCALE;
-                *(uint32_t*)d8 = pk4_bf8(y[0], y[1], y[2], y[3]);
-                *(uint32_t*)(d8 + (size_t)rows * C) = pk4_bf8(k * (float)lv[0], k * (float)lv[1], k * (float)lv[2], k * (float)lv[3]);
+              if constexpr (DT == VDN_F16) {
+                if (out8) {  // staged for the 6-bit rows below: this wave's row as fp16 hi and remainder
+                  *(f16x4*)(stage + c) = hv;
+                  *(f16x4*)(stage + NV * 256 + c) = lv;
+                }
               }
             } else {
 #pragma unroll
@@ -104,6 +106,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
             }
             *(typename Half<DT>::V4*)(out_h + oh) = hv;
           }
+        }
+      }
+      if constexpr (DT == VDN_F16) {
+        if (out8) {
+          // 6-bit rows of the consuming GEMM's A operand (common.hpp x6 rows, natural order): the row goes through LDS so that a
+          // lane holds the 32 consecutive values of one half; lanes take (plane, half) pairs: hi rows first, then remainder rows
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own staging writes (LDS is in order per wave)
+          const int nb = C >> 5;
+          for (int t = lane; t < 2 * nb; t += 64) {
+            const int plane = t >= nb, hb = t - plane * nb;
+            f16x32 hv, xv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f16x8 a = *(const f16x8*)(stage + hb * 32 + 8 * q);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) hv[8 * q + e] = a[e];
+            }
+            const int sb = x6_scale_byte(hv);
+            if (plane) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f16x8 a = *(const f16x8*)(stage + NV * 256 + hb * 32 + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[8 * q + e] = a[e];
+              }
+            } else xv = hv;
+            uint8_t* d8 = out8 + (size_t)plane * rows * C +
+                          (kt ? ((size_t)(hb >> 1) * rows + orow) * 64 + 32 * (hb & 1) : orow * C + (size_t)hb * 32);
+            x6_store_half(d8, xv, plane ? sb - 10 : sb);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next row overwrites it
         }
       }
     }

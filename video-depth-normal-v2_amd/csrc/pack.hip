@@ -132,33 +132,46 @@ extern "C" int vdn_pack_bias(int kind, const float* b, int d0, int d1, int d2, f
 }
 
 namespace {
-// Operand planes of the 8-bit cross-term GEMM from packed fp16 split planes (include/vdn.h: vdn_pack_x8): the hi plane again
-// K-tile-major and the two e5m2 planes (value, remainder 2^10), K-tile-major or row-major. One thread per 4 elements.
+// Operand planes of the 8-bit cross-term GEMM from fp16 split planes (include/vdn.h: vdn_pack_x8): the hi plane again
+// K-tile-major and the two planes of 6-bit rows (hi, remainder; common.hpp 'x6 rows'), K-tile-major or row-major. One thread
+// per row, 64-wide K slab and half: 32 values gathered in the stream order of the activation's producer.
 __global__ __launch_bounds__(256) void pack_x8_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int rows,
-                                                      int ld, _Float16* __restrict__ hi_kt, uint8_t* __restrict__ p8, int kt) {
-  const size_t total = (size_t)rows * (ld >> 2);
+                                                      int ld, _Float16* __restrict__ hi_kt, uint8_t* __restrict__ p8, int kt, int order) {
+  const size_t total = (size_t)rows * (ld >> 5);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int r = (int)(i / (ld >> 2)), k = (int)(i - (size_t)r * (ld >> 2)) * 4;
-    const f16x4 h = *(const f16x4*)(hi + (size_t)r * ld + k);
-    const f16x4 l = *(const f16x4*)(lo + (size_t)r * ld + k);
-    if (hi_kt) *(f16x4*)(hi_kt + ((size_t)(k >> 5) * rows + r) * 32 + (k & 31)) = h;
-    const size_t o8 = kt ? ((size_t)(k >> 6) * rows + r) * 64 + (k & 63) : (size_t)r * ld + k;
-    const float s = VDN_LO8_SCALE;
-    *(uint32_t*)(p8 + o8) = pk4_bf8((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
-    *(uint32_t*)(p8 + (size_t)rows * ld + o8) = pk4_bf8(s * (float)l[0], s * (float)l[1], s * (float)l[2], s * (float)l[3]);
+    const int r = (int)(i / (ld >> 5)), hb = (int)(i - (size_t)r * (ld >> 5)), slab = hb >> 1, h = hb & 1;
+    const _Float16* hr = hi + (size_t)r * ld + slab * 64;
+    const _Float16* lr = lo + (size_t)r * ld + slab * 64;
+    f16x32 hv, lv;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      const int c = x6_col(order, h, p);
+      hv[p] = hr[c];
+      lv[p] = lr[c];
+    }
+    if (hi_kt) {  // natural column order: K tile 2 slab + h of this row
+      _Float16* d = hi_kt + ((size_t)(2 * slab + h) * rows + r) * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(f16x8*)(d + 8 * q) = *(const f16x8*)(hr + 32 * h + 8 * q);
+    }
+    const int sb = x6_scale_byte(hv);
+    uint8_t* d8 = p8 + (kt ? ((size_t)slab * rows + r) * 64 + 32 * h : (size_t)r * ld + slab * 64 + 32 * h);
+    x6_store_half(d8, hv, sb);
+    x6_store_half(d8 + (size_t)rows * ld, lv, sb - 10);
   }
 }
 
 }  // namespace
 
-extern "C" int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, vdn_stream stream) {
-  if (!hi || !lo || !planes8 || rows <= 0 || ld <= 0 || (ld & 63)) return VDN_EINVAL;
+extern "C" int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, int order,
+                           vdn_stream stream) {
+  if (!hi || !lo || !planes8 || rows <= 0 || ld <= 0 || (ld & 63) || order < 0 || order > 2) return VDN_EINVAL;
   if (((uintptr_t)hi | (uintptr_t)lo | (uintptr_t)hi_kt | (uintptr_t)planes8) & 15) return VDN_EALIGN;
   if (hi_kt && !kt) return VDN_EINVAL;
-  const size_t work = (size_t)rows * (ld >> 2);
+  const size_t work = (size_t)rows * (ld >> 5);
   const dim3 g((unsigned)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192));
   hipLaunchKernelGGL(pack_x8_kernel, g, dim3(256), 0, (hipStream_t)stream, (const _Float16*)hi, (const _Float16*)lo, rows, ld,
-                     (_Float16*)hi_kt, (uint8_t*)planes8, kt);
+                     (_Float16*)hi_kt, (uint8_t*)planes8, kt, order);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }

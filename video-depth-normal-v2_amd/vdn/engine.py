@@ -64,7 +64,8 @@ class EncoderEngine:
                    and os.environ.get("VDN_X8", "1") != "0")
         if self.x8:
             for blk in self.blocks:
-                blk["x8"] = {k: pack.X8(blk[k]) for k in ("wqkv", "wproj", "wfc1", "wfc2")}
+                blk["x8"] = {k: pack.X8(blk[k], o) for k, o in (("wqkv", pack.ORDER_NATURAL), ("wproj", pack.ORDER_ATTN),
+                                                                   ("wfc1", pack.ORDER_NATURAL), ("wfc2", pack.ORDER_GEMM))}
         # per-layer precision budget (include/vdn.h x8_terms; profiles/r03_precision_budget.md): VDN_X8_TERMS = "fc2=1,proj=1@12-23"
         # drops a cross term of the named linears (1: A_lo W_hi^T, 2: A_hi W_lo^T), optionally for blocks a..b only
         self.x8_terms = [dict(qkv=0, proj=0, fc1=0, fc2=0) for _ in self.blocks]
@@ -537,9 +538,10 @@ class MemoryEngine:
         self.x8 = rt.split and rt.half == torch.float16 and C % 64 == 0 and os.environ.get("VDN_X8", "1") != "0"
         if self.x8:
             for L in self.layers:
-                L["x8"] = {k: pack.X8(L[k]) for k in ("wqkv", "wso", "wq", "wco", "w1", "w2")}
+                L["x8"] = {k: pack.X8(L[k], o) for k, o in (("wqkv", pack.ORDER_NATURAL), ("wso", pack.ORDER_ATTN), ("wq", pack.ORDER_NATURAL),
+                                                            ("wco", pack.ORDER_ATTN), ("w1", pack.ORDER_NATURAL), ("w2", pack.ORDER_GEMM))}
             for cx in self.cx:
-                cx["x8"] = {k: pack.X8(cx[k]) for k in ("w1", "w2")}
+                cx["x8"] = {"w1": pack.X8(cx["w1"], pack.ORDER_NATURAL), "w2": pack.X8(cx["w2"], pack.ORDER_GEMM)}
         # Bank state shared by every lane copy of this engine (DepthAnythingV2._stream_lanes): ONE ring for the whole
         # batch, lane i of n works on batch rows [i B/n, (i+1) B/n) of it, so laned and single-lane calls see the
         # same memory and `count` advances once per forward (commit()).

@@ -138,29 +138,70 @@ def cat_proj(ws, bs, ropes, half) -> Tuple[torch.Tensor, Optional[torch.Tensor]]
     return out, bias
 
 
-def planes8(t) -> torch.Tensor:
-    """HL [rows, ld] (ld % 64 == 0) -> u8 [2, rows, ld]: e5m2(value) and e5m2(remainder * 2^10), the operand planes of
-    the 8-bit cross-term GEMM (include/vdn.h A8 / W8)."""
+ORDER_NATURAL, ORDER_GEMM, ORDER_ATTN = 0, 1, 2   # include/vdn.h vdn_pack_x8: who writes the A planes of the GEMM
+
+
+def planes8(t, order: int = ORDER_NATURAL, kt: bool = False) -> torch.Tensor:
+    """HL [rows, ld] (ld % 64 == 0) -> u8 [2, rows, ld]: the x6 rows (e3m2 codes + E8M0 scale per 32 values) of the hi plane
+    and of the remainder plane, the operand planes of the cross-term GEMM (include/vdn.h A8 / W8), made on the device by
+    vdn_pack_x8; kt: K-tile-major ([ld/64][rows][64] per plane)."""
+    from . import _abi as abi
     rows, ld = t.hi.shape
-    assert ld % 64 == 0 and t.lo is not None
-    v8 = t.float().to(torch.float8_e5m2).view(torch.uint8)
-    l8 = (t.lo.float() * 1024.0).to(torch.float8_e5m2).view(torch.uint8)
-    return torch.stack([v8, l8]).contiguous()
+    assert ld % 64 == 0 and t.lo is not None and t.hi.dtype == torch.float16
+    p8 = torch.empty((2, rows, ld), dtype=torch.uint8, device=t.hi.device)
+    abi.check(abi.lib.vdn_pack_x8(t.hi.data_ptr(), t.lo.data_ptr(), rows, ld, None, p8.data_ptr(), int(kt), order, _stream(t.hi)),
+              "vdn_pack_x8")
+    return p8
+
+
+def x6_columns(order: int) -> torch.Tensor:
+    """[2, 32]: the column of a 64-wide slab at stream position p of half h (include/vdn.h vdn_pack_x8 `order`)."""
+    h, p = torch.arange(2)[:, None], torch.arange(32)[None, :]
+    if order == ORDER_GEMM:
+        return 32 * (p >> 4) + 16 * ((p >> 3) & 1) + 8 * h + (p & 7)
+    if order == ORDER_ATTN:
+        return 32 * (p >> 4) + 8 * ((p >> 2) & 3) + 4 * h + (p & 3)
+    return 32 * h + p
+
+
+def decode6(plane: torch.Tensor, rows: int, K: int, order: int = ORDER_NATURAL, kt: bool = False) -> torch.Tensor:
+    """The values one plane of x6 rows stands for, f32 [rows, K] in natural column order (tests and tools: what the MFMA sees)."""
+    b = plane.reshape(K // 64, rows, 2, 32) if kt else plane.reshape(rows, K // 64, 2, 32).permute(1, 0, 2, 3)
+    b = b.to(torch.int64)                                              # [slab, row, half, 32 bytes]
+    words = [sum(b[..., 8 * w + i] << (8 * i) for i in range(8)) for w in range(3)]   # the 24 code bytes as three 64-bit words
+    codes = []
+    for p in range(32):
+        bit = 6 * p
+        w, o = bit // 64, bit % 64
+        v = (words[w] >> o) & 63 if o <= 58 else ((words[w] >> o) & ((1 << (64 - o)) - 1)) | ((words[w + 1] & ((1 << (o - 58)) - 1)) << (64 - o))
+        codes.append(v & 63)
+    c = torch.stack(codes, dim=-1)                                     # [slab, row, half, 32]
+    sign, e, m = (c >> 5) & 1, (c >> 2) & 7, c & 3
+    val = torch.where(e > 0, (1.0 + 0.25 * m.double()) * torch.pow(2.0, (e - 3).double()), 0.25 * m.double() * 0.25)
+    val = torch.where(sign > 0, -val, val) * torch.pow(2.0, (b[..., 24] - 127).double())[..., None]
+    out = torch.empty(rows, K, dtype=torch.float64, device=plane.device)
+    cols = x6_columns(order).to(plane.device)                          # [2, 32]
+    for s in range(K // 64):
+        for h in range(2):
+            out[:, 64 * s + cols[h]] = val[s, :, h, :]
+    return out.float()
 
 
 class X8:
-    """Weight planes of the 8-bit cross-term GEMM (include/vdn.h W8 / w_kt): the fp16 hi plane K-tile-major
-    ([ld/32][N][32]) and the two e5m2 planes u8 [2][ld/64][N][64], made on the device by vdn_pack_x8."""
-    __slots__ = ("hi", "p8", "rows", "ld")
+    """Weight planes of the cross-term GEMM (include/vdn.h W8 / w_kt): the fp16 hi plane K-tile-major ([ld/32][N][32]) and
+    the two planes of x6 rows u8 [2][ld/64][N][64], made on the device by vdn_pack_x8 in the stream ORDER of the kernel that
+    writes the GEMM's activation planes."""
+    __slots__ = ("hi", "p8", "rows", "ld", "order")
 
-    def __init__(self, w):
+    def __init__(self, w, order: int = ORDER_NATURAL):
         from . import _abi as abi
         assert w.lo is not None and w.hi.dtype == torch.float16 and w.hi.shape[1] % 64 == 0
         self.rows, self.ld = w.hi.shape
+        self.order = order
         self.hi = torch.empty_like(w.hi)
         self.p8 = torch.empty((2, self.rows, self.ld), dtype=torch.uint8, device=w.hi.device)
         abi.check(abi.lib.vdn_pack_x8(w.hi.data_ptr(), w.lo.data_ptr(), self.rows, self.ld, self.hi.data_ptr(),
-                                      self.p8.data_ptr(), 1, _stream(w.hi)), "vdn_pack_x8")
+                                      self.p8.data_ptr(), 1, order, _stream(w.hi)), "vdn_pack_x8")
 
 
 def rope_table(side_y: int, side_x: int, dim: int = 64, theta: float = 10000.0, device=None) -> torch.Tensor:
