@@ -421,7 +421,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": ("gemm_x8_kernel<256|192 x 256 x 64> on the 4 encoder linears (qkv, proj, fc1, fc2): A_hi W_hi^T on fp16 MFMAs + the two "
-                           "split-precision cross terms on the block-scaled e5m2 MFMA, K-tile-major planes" if x8 else
+                           "split-precision cross terms on the block-scaled MFMA from 6-bit (e3m2 + E8M0 per 32) K-tile-major planes" if x8 else
                            "gemm_x3_p8_kernel<256x256x32> (fc1) / gemm_x3_big_kernel<192x256x32> (qkv, proj, fc2): the 4 encoder linears" if nprod == 3
                            else "gemm_kernel<128x128x64> on the 4 encoder linears (qkv, proj, fc1, fc2)"),
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
@@ -429,10 +429,10 @@ def main():
                 "peak_measured_source": "profiles/r02_mfma_scale_probe.log (register-only fp16 32x32x16 loop on the box: what the power-managed clock sustains)",
                 "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(lin),
                 "avg_launch_ms": round(tot_ms / len(lin), 4), "algorithmic_gflop_per_launch": round(tot_fl / len(lin) / 1e9, 2)}
-            # matrix-pipe work actually issued per algorithmic product: 3 fp16 products (x3), or 1 fp16 + 2 e5m2 products that the
-            # scaled MFMA runs at 2.32x the fp16 rate (measured, same probe) = 1.86 fp16-product equivalents
-            eq = (1.0 + 2.0 / 2.32) if x8 else float(nprod)
-            out["roofline"].update({"mfma_products_per_term": ("1 fp16 + 2 e5m2 (block-scaled, 2.32x rate)" if x8 else nprod),
+            # matrix-pipe work actually issued per algorithmic product: 3 fp16 products (x3), or 1 fp16 + 2 e3m2 products that the
+            # scaled MFMA runs at 4.19x the fp16 rate (measured, same probe) = 1.48 fp16-product equivalents
+            eq = (1.0 + 2.0 / 4.19) if x8 else float(nprod)
+            out["roofline"].update({"mfma_products_per_term": ("1 fp16 + 2 e3m2 (block-scaled 6-bit, 4.19x rate)" if x8 else nprod),
                                     "fp16_product_equivalents": round(eq, 2), "executed_frac": round(eq * ach / PEAK_TFLOPS_F16, 4),
                                     "executed_frac_of_measured": round(eq * ach / PEAK_MEASURED_TFLOPS_F16, 4)})
             if dt1 is not None:

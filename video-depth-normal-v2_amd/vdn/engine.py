@@ -127,7 +127,7 @@ class EncoderEngine:
         use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096")) and q8 is not None and rt.pv_products != 3
         if use8:
             from .runtime import HL
-            # activations between the linears as K-tile-major planes: fp16 hi + e5m2 (value, remainder) — no fp16 lo plane
+            # activations between the linears as K-tile-major planes: fp16 hi + the 6-bit rows of hi and remainder — no fp16 lo plane
             hn_k, hn8 = HL(rt.buf("enc_ln_kt", (M, C), rt.half)), rt.buf("enc_ln8", (2, M, C), torch.uint8)
             att_k, att8 = HL(rt.buf("enc_att_kt", (M, C), rt.half)), rt.buf("enc_att8", (2, M, C), torch.uint8)
             f1_k, f18 = HL(rt.buf("enc_fc1_kt", (M, Hd), rt.half)), rt.buf("enc_fc18", (2, M, Hd), torch.uint8)
@@ -636,7 +636,7 @@ class MemoryEngine:
                   tokens=P, tpad=pp)
         qh = dict(dst=[rt.qk_dst(q, q8)], dst8=[q8], transposed=[0], rope=[1], rope_cs=cs, rope_mod=P, heads=Hh, tokens=P, tpad=pp)
         use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096")) and q8 is not None and rt.pv_products != 3
-        if use8:   # K-tile-major fp16 hi + e5m2 planes between the linears (no fp16 lo plane), as in EncoderEngine.run
+        if use8:   # K-tile-major fp16 hi + planes of 6-bit rows between the linears (no fp16 lo plane), as in EncoderEngine.run
             from .runtime import HL
             n_k, n8 = HL(rt.buf("ma_n_kt", (M, C), rt.half)), rt.buf("ma_n8", (2, M, C), torch.uint8)
             att_k, att8 = HL(rt.buf("ma_att_kt", (M, C), rt.half)), rt.buf("ma_att8", (2, M, C), torch.uint8)

@@ -236,7 +236,7 @@ class Runtime:
     def layernorm(self, x: torch.Tensor, rows: int, Cn: int, w, b, eps: float, *, out_h=None, out_f=None, addvec=None,
                   alpha: float = 1.0, addtab=None, tab_div: int = 1, tab_mod: int = 1, out_group: int = 0, out8=None,
                   kt: bool = False):
-        """out8: u8 [2, rows, C] e5m2 planes of the output for the 8-bit cross-term GEMM; kt: K-tile-major planes."""
+        """out8: u8 [2, rows, C] planes of 6-bit rows of the output for the cross-term GEMM (include/vdn.h A8); kt: K-tile-major planes."""
         oh, ol = _hl(out_h) if out_h is not None else (None, None)
         self._launch(abi.lib.vdn_layernorm, x.data_ptr(), _TDT[x.dtype], rows, Cn, w.data_ptr(), b.data_ptr(), eps,
                      self._p(addvec), alpha, self._p(addtab), tab_div, tab_mod, out_group, self._p(oh), ol, self.dt,
@@ -246,7 +246,7 @@ class Runtime:
                    tag: Optional[str] = None, q8: Optional[torch.Tensor] = None, k8: Optional[torch.Tensor] = None,
                    out8: Optional[torch.Tensor] = None, out_kt: bool = False):
         """q8 / k8: the u8 [B*H, n_pad, 128] planes the projection wrote through heads['dst8'] (8-bit cross terms).
-        out8 / out_kt: e5m2 planes of the output and the K-tile-major layout for the 8-bit cross-term GEMM that follows."""
+        out8 / out_kt: planes of 6-bit rows of the output and the K-tile-major layout for the cross-term GEMM that follows."""
         (Q, ql), (K, kl), (Vt, vl), (out, ol) = _hl(Q), _hl(K), _hl(Vt), _hl(out)
         self._launch(abi.lib.vdn_flash_attn, self.dt, Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), ql, kl,
                      vl, ol, self._p(q8), self._p(k8), self._p(out8), int(out_kt), B, H, nq, nq_pad, nk, nk_pad, scale, self.pv_products, tag=tag,

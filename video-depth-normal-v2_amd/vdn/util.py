@@ -109,7 +109,7 @@ def release_host_buffers():
 def check_finite(t: torch.Tensor, what: str):
     """Loud range check of a driver's result before it leaves the device (one reduction next to the copy that synchronises
     anyway). 16-bit operand planes are fp16: an activation beyond +-1.3e5 (hi saturates at 65 504, lo carries the next
-    65 504) — +-5.7e4 on the 8-bit cross-term path, whose e5m2 planes top out there — turns into inf / NaN and reaches the
+    65 504) turns into inf / NaN and reaches the
     depth map; no checkpoint the reference ships comes near (INTEGRATION.md 'Range'). VDN_PRECISION=bf16x3 has fp32's range."""
     if not bool(torch.isfinite(t).all()):
         raise FloatingPointError(
