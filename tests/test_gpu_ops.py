@@ -1130,6 +1130,32 @@ def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
         close(y, (refg.double() @ w2.double().t()).float(), 6e-5)   # the input planes (2^-14) and the product's own cross terms
 
 
+def test_x8_gemm_outlier_channels_zero_rows_and_large_values(rt3):
+    """The block-scaled 6-bit rows where their scale matters: activation channels 200x above their neighbours (the 31 other
+    values of such a half fall into the subnormal codes: only their CROSS terms lose precision), all-zero rows, and values
+    near the top of fp16 (6e4: above what the earlier e5m2 planes could carry): against fp64 and against the
+    three-fp16-product kernel."""
+    from vdn import pack
+    M, N, K = 4100, 1024, 1024
+    a = rnd(M, K, seed=1200)
+    a[:, [5, 77, 300, 301, 1000]] *= 200.0
+    a[17] = 0.0
+    a[100:164] = 0.0
+    a[200, 64:128] = 6.0e4 * torch.sign(a[200, 64:128])
+    w = rnd(N, K, seed=1201, scale=1 / math.sqrt(K))
+    w[:, 5] *= 30.0
+    b = rnd(N, seed=1202)
+    ref = (a.double() @ w.double().t() + b.double()).float()
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    out8, out3 = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    rt3.gemm(A, W, M, N, K, out=out8, bias=b.to(DEV), a8=pack.planes8(A), w8=pack.planes8(W))
+    rt3.gemm(A, W, M, N, K, out=out3, bias=b.to(DEV))
+    close(out3, ref, 2e-5)
+    close(out8, ref, 3e-5)
+    assert torch.equal(out8[17].cpu(), b) and torch.equal(out8[100:164].cpu(), b.expand(64, N))   # zero rows: exactly the bias
+    _check_x6(pack.planes8(A), A, M, K, pack.ORDER_NATURAL)
+
+
 @pytest.mark.parametrize("rows,C", [(77, 384), (1370, 1024), (300, 64)])
 def test_layernorm_8bit_planes_and_k_tile_major(rt3, rows, C):
     """vdn_layernorm(out8, kt): the hi plane + the planes of 6-bit rows of the cross-term GEMM's A operand, row-major and
