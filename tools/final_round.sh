@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-end evidence on the GPU box (after tools/gpu_round.sh): PMC traffic of the dominant kernels, SQ counters of the cross-term
+# GEMM under tools/x8_bench.py, the race screen, and the bench lines of the other workloads. Outputs under gpurun_out/.
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 bash tools/pmc_traffic.sh r03 > gpurun_out/r03_pmc_traffic.stdout 2>&1 || echo "pmc traffic failed"
