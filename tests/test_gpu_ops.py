@@ -1130,6 +1130,24 @@ def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
         close(y, (refg.double() @ w2.double().t()).float(), 6e-5)   # the input planes (2^-14) and the product's own cross terms
 
 
+@pytest.mark.parametrize("terms", [1, 2])
+def test_x8_gemm_dropped_cross_term(rt3, terms):
+    """vdn_gemm_desc.x8_terms: 1 leaves out A_lo W_hi^T, 2 leaves out A_hi W_lo^T (the scale byte of that plane is zeroed in
+    the kernel, no branch): the result is the full product minus exactly that term."""
+    from vdn import pack
+    M, N, K = 4100, 512, 1024
+    a, w = rnd(M, K, seed=1210), rnd(N, K, seed=1211, scale=1 / math.sqrt(K))
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    ah, al, wh, wl = A.hi.double().cpu(), A.lo.double().cpu(), W.hi.double().cpu()[:, :K], W.lo.double().cpu()[:, :K]
+    full = (ah + al) @ (wh + wl).t()
+    dropped = al @ wh.t() if terms == 1 else ah @ wl.t()
+    out = torch.zeros(M, N, device=DEV)
+    rt3.gemm(A, W, M, N, K, out=out, a8=pack.planes8(A), w8=pack.planes8(W), x8_terms=terms)
+    close(out, (full - dropped).float(), 3e-5)
+    err_full = ((out.cpu().double() - full).norm() / full.norm()).item()
+    assert 1e-4 < err_full < 1e-3, err_full          # the missing term is 2^-11-sized: visible, as the budget experiment found
+
+
 def test_x8_gemm_outlier_channels_zero_rows_and_large_values(rt3):
     """The block-scaled 6-bit rows where their scale matters: activation channels 200x above their neighbours (the 31 other
     values of such a half fall into the subnormal codes: only their CROSS terms lose precision), all-zero rows, and values
