@@ -608,13 +608,10 @@ class MemoryEngine:
         pp = ceil_to(P, 64)
         x = rt.fbuf("ma_x", (M, C))
         rt.add_vec(feat_f32, self.curr_pos, 0.1, x, M, C)  # memory_attention.py:140-141
-        n = rt.hbuf("ma_n", (M, C))
         q = rt.hbuf("ma_q", (B * Hh, pp, 64), zero=True)
         k = rt.hbuf("ma_k", (B * Hh, pp, 64), zero=True)
         vt = rt.hbuf("ma_vt", (B * Hh, 64, pp), zero=True)
         q8, k8 = rt.qk8("ma_q8", B * Hh, pp), rt.qk8("ma_k8", B * Hh, pp)
-        att = rt.hbuf("ma_att", (M, C))
-        h2 = rt.hbuf("ma_h2", (M, 2 * C))
         ks, vs, k8s, tp = self._bank(B, P)
         S = self.S
         if S == 0:
@@ -658,6 +655,7 @@ class MemoryEngine:
             out = rt.hbuf("mem_out", (M, C))
             rt.layernorm(x, M, C, self.nw, self.nb, 1e-5, out_h=out)
             return out
+        n, att, h2 = rt.hbuf("ma_n", (M, C)), rt.hbuf("ma_att", (M, C)), rt.hbuf("ma_h2", (M, 2 * C))   # split planes of the 3-product path
         for l, L in enumerate(self.layers):
             rt.layernorm(x, M, C, L["n1w"], L["n1b"], 1e-5, out_h=n)
             rt.gemm(n, L["wqkv"], M, 3 * C, C, bias=L["bqkv"], store=abi.ST_HEADS, heads=sh)
@@ -690,14 +688,14 @@ class MemoryEngine:
         x = rt.fbuf("me_x", (M, C))
         rt.gemm(mem_out, self.wpix, M, C, C, bias=self.bpix, rowadd=m2, out=x)
         d = rt.fbuf("me_dw", (M, C))
-        n = rt.hbuf("me_n", (M, C))
-        h4 = rt.hbuf("me_h4", (M, 4 * C))
         feat = rt.hbuf("mem_feat", (M, C))
         use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096"))
         if use8:
             from .runtime import HL
             n_k, n8 = HL(rt.buf("me_n_kt", (M, C), rt.half)), rt.buf("me_n8", (2, M, C), torch.uint8)
             h4_k, h48 = HL(rt.buf("me_h4_kt", (M, 4 * C), rt.half)), rt.buf("me_h48", (2, M, 4 * C), torch.uint8)
+        else:
+            n, h4 = rt.hbuf("me_n", (M, C)), rt.hbuf("me_h4", (M, 4 * C))
         for j, cx in enumerate(self.cx):
             rt.dwconv7(x, d, B, ph, pw, C, cx["wdw"], cx["bdw"])
             if use8:
