@@ -13,7 +13,9 @@ template <> struct Vec4<__bf16> { using V = bf16x4; };
 // current one, so two rows (8 KiB at C = 1024) per wave are in flight and the grid (<= 8 blocks per CU) has no
 // partial last round: round 1 ran one row per wave with 2740 blocks on 2048 slots (1.34 rounds of pure latency)
 // at 2.7 TB/s. gamma / beta (+ alpha * addvec) are loaded once per wave. NV = 256-channel steps (4 per lane each).
-template <typename XT, int DT, int NV>
+// X6: the launch also writes the planes of 6-bit rows (out8) — a separate instantiation, so that the plain one keeps its register
+// count and occupancy (the staging + conversion code cost a block per CU when it was compiled into every launch)
+template <typename XT, int DT, int NV, bool X6>
 __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, int rows, int C,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, const float* __restrict__ addvec, float alpha,
@@ -25,8 +27,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
   using XV = typename Vec4<XT>::V;
   const int lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
-  __shared__ __attribute__((aligned(16))) _Float16 stage_all[DT == VDN_F16 ? 4 * 2 * NV * 256 : 8];   // out8: per wave, hi and remainder of a row
-  _Float16* const stage = stage_all + (DT == VDN_F16 ? (threadIdx.x >> 6) * 2 * NV * 256 : 0);
+  extern __shared__ __attribute__((aligned(16))) _Float16 stage_all[];   // X6: per wave, hi and remainder of a row (4 x 2 x NV x 256 halves)
+  _Float16* const stage = stage_all + (X6 ? (threadIdx.x >> 6) * 2 * NV * 256 : 0);
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   f32x4 wv[NV], bv[NV];
 #pragma unroll
@@ -94,11 +96,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
                 hv[e] = h0; hv[e + 1] = h1; lv[e] = l0; lv[e + 1] = l1;
               }
               if (out_l) *(typename Half<DT>::V4*)(out_l + oh) = lv;
-              if constexpr (DT == VDN_F16) {
-                if (out8) {  // staged for the 6-bit rows below: this wave's row as fp16 hi and remainder
-                  *(f16x4*)(stage + c) = hv;
-                  *(f16x4*)(stage + NV * 256 + c) = lv;
-                }
+              if constexpr (X6 && DT == VDN_F16) {   // staged for the 6-bit rows below: this wave's row as fp16 hi and remainder
+                *(f16x4*)(stage + c) = hv;
+                *(f16x4*)(stage + NV * 256 + c) = lv;
               }
             } else {
 #pragma unroll
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
           }
         }
       }
-      if constexpr (DT == VDN_F16) {
-        if (out8) {
+      if constexpr (X6 && DT == VDN_F16) {
+        {
           // 6-bit rows of the consuming GEMM's A operand (common.hpp x6 rows, natural order): the row goes through LDS so that a
           // lane holds the 32 consecutive values of one half; lanes take (plane, half) pairs: hi rows first, then remainder rows
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own staging writes (LDS is in order per wave)
@@ -296,19 +296,32 @@ int ln_launch_nv(const void* x, int rows, int C, const float* w, const float* b,
   static const int resident = [] {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layernorm_kernel<XT, VDN_F16, NV>, 256, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layernorm_kernel<XT, VDN_F16, NV, false>, 256, 0) != hipSuccess || per_cu <= 0)
       per_cu = 4;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * per_cu;
     return prop.multiProcessorCount * per_cu;
   }();
+  constexpr size_t lds6 = (size_t)4 * 2 * NV * 256 * sizeof(_Float16);
+  static const int resident6 = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layernorm_kernel<XT, VDN_F16, NV, true>, 256, lds6) != hipSuccess || per_cu <= 0)
+      per_cu = 3;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * per_cu;
+    return prop.multiProcessorCount * per_cu;
+  }();
   const int blocks = (rows + 3) / 4;
-  const dim3 grid(blocks < resident ? blocks : resident);
+  const int res = out8 ? resident6 : resident;
+  const dim3 grid(blocks < res ? blocks : res);
   if (h_dt == VDN_BF16)
-    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16, NV>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_BF16, NV, false>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
                        addvec, alpha, addtab, tab_div, tab_mod, out_group, (__bf16*)out_h, (__bf16*)out_l, out_f, (uint8_t*)nullptr, 0);
-  else
-    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16, NV>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+  else if (out8)
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16, NV, true>), grid, dim3(256), lds6, s, (const XT*)x, rows, C, w, b, eps,
                        addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f, (uint8_t*)out8, kt);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<XT, VDN_F16, NV, false>), grid, dim3(256), 0, s, (const XT*)x, rows, C, w, b, eps,
+                       addvec, alpha, addtab, tab_div, tab_mod, out_group, (_Float16*)out_h, (_Float16*)out_l, out_f, (uint8_t*)nullptr, kt);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }
