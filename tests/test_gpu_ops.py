@@ -1130,6 +1130,29 @@ def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
         close(y, (refg.double() @ w2.double().t()).float(), 6e-5)   # the input planes (2^-14) and the product's own cross terms
 
 
+@pytest.mark.parametrize("M,N,K", [(5500, 192, 128), (4200, 320, 1024), (4099, 448, 64)])
+def test_x8_gemm_column_tail_tiles(rt3, M, N, K, tune):
+    """Column counts that leave the last 256-wide tile partly empty (W rows clamped on load, columns masked on store), with
+    ragged M: residual flavour and the bias + GELU flavour with its 6-bit output rows; both tile heights."""
+    from vdn import pack, _abi
+    from vdn.runtime import HL
+    a, w = rnd(M, K, seed=1220), rnd(N, K, seed=1221, scale=1 / math.sqrt(K))
+    b, x = rnd(N, seed=1222), rnd(M, N, seed=1223)
+    ref = (x.double() + a.double() @ w.double().t() + b.double()).float()
+    refg = F.gelu(a.double() @ w.double().t() + b.double()).float()
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    Ak, A8k, X = HL(_kt16(A.hi, M, K)), pack.planes8(A, kt=True), pack.X8(W)
+    for bm in (192, 256):
+        tune(force_bm=bm)
+        xo = x.clone().to(DEV)
+        rt3.gemm(Ak, HL(X.hi), M, N, K, out=xo, bias=b.to(DEV), res1=xo, a8=A8k, w8=X.p8, a_kt=True, w_kt=True)
+        close(xo, ref, 2e-5)
+        oh = HL(torch.zeros(M, N, dtype=torch.float16, device=DEV))
+        o8 = torch.full((2, M, N), 0xA5, dtype=torch.uint8, device=DEV)
+        rt3.gemm(Ak, HL(X.hi), M, N, K, out=oh, bias=b.to(DEV), act=_abi.ACT_GELU, a8=A8k, w8=X.p8, out8=o8, a_kt=True, w_kt=True, out_kt=True)
+        close(_unkt16(oh.hi, M, N).float() + pack.decode6(o8[1], M, N, pack.ORDER_GEMM, kt=True), refg, 3e-5)
+
+
 @pytest.mark.parametrize("terms", [1, 2])
 def test_x8_gemm_dropped_cross_term(rt3, terms):
     """vdn_gemm_desc.x8_terms: 1 leaves out A_lo W_hi^T, 2 leaves out A_hi W_lo^T (the scale byte of that plane is zeroed in
