@@ -1130,6 +1130,45 @@ def test_x8_gemm_k_tile_major_planes(rt3, M, N, K, bm, tune):
         close(y, (refg.double() @ w2.double().t()).float(), 6e-5)   # the input planes (2^-14) and the product's own cross terms
 
 
+@pytest.mark.parametrize("bm", [192, 256])
+def test_x8_heads_split_with_attention_planes(rt3, bm, tune):
+    """The QKV head split on the cross-term kernel (paired epilogue): Q / K hi planes, V^T, and the attention's 8-bit planes
+    (64 B e5m2(v) | 64 B e5m2(remainder 2^10) per token and head, natural channel order: the two lanes of a token swap halves and
+    store 32-byte runs) — against the same launch on the three-product kernel and against fp64."""
+    from vdn import pack, _abi
+    from vdn.runtime import ceil_to
+    tune(force_bm=bm)
+    B, T, Hh, K = 3, 1370, 2, 128
+    C, tp, M = Hh * 64, ceil_to(1370, 64), 3 * 1370
+    a = rnd(M, K, seed=1230)
+    w, b = rnd(3 * C, K, seed=1231, scale=1 / math.sqrt(K)), rnd(3 * C, seed=1232)
+    A, W = rt3.to_half(a.to(DEV)), pack.linear(w.to(DEV), rt3.prec)
+    outs = []
+    for x8 in (False, True):
+        q, k = rt3.hbuf(f"t_hs_q{x8}", (B * Hh, tp, 64), zero=True), rt3.hbuf(f"t_hs_k{x8}", (B * Hh, tp, 64), zero=True)
+        vt = rt3.hbuf(f"t_hs_v{x8}", (B * Hh, 64, tp), zero=True)
+        q8, k8 = rt3.qk8(f"t_hs_q8{x8}", B * Hh, tp), rt3.qk8(f"t_hs_k8{x8}", B * Hh, tp)
+        q8.zero_(); k8.zero_()
+        kw = dict(a8=pack.planes8(A), w8=pack.planes8(W)) if x8 else {}
+        rt3.gemm(A, W, M, 3 * C, K, bias=b.to(DEV), store=_abi.ST_HEADS,
+                 heads=dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=T, tpad=tp), **kw)
+        outs.append((q, k, vt, q8, k8))
+    (q3, k3, v3, _, _), (q, k, vt, q8, k8) = outs
+    close(q.float(), q3.float(), 2e-5)
+    close(vt.float(), v3.float(), 2e-5)
+    ref = (a.double() @ w.double().t() + b.double()).float().reshape(B, T, 3, Hh, 64)
+    for got, idx in ((q, 0), (k, 1)):
+        close(got.float().reshape(B, Hh, tp, 64)[:, :, :T], ref[:, :, idx].transpose(1, 2), 2e-5)
+    close(vt.float().reshape(B, Hh, 64, tp)[..., :T], ref[:, :, 2].permute(0, 2, 3, 1), 2e-5)
+    for p8, planes in ((q8, q), (k8, k)):
+        want_hi = planes.float()[:, :T].to(torch.float8_e5m2).view(torch.uint8)
+        want_lo = (planes.lo.float()[:, :T] * 1024.0).to(torch.float8_e5m2).view(torch.uint8) if planes.lo is not None else None
+        got = p8[:, :T]
+        assert (got[..., :64].int() - want_hi.int()).abs().max() <= 1 and (got[..., :64] != want_hi).float().mean() < 2e-3
+        if want_lo is not None:
+            assert torch.equal(got[..., 64:], want_lo)
+
+
 @pytest.mark.parametrize("M,N,K", [(5500, 192, 128), (4200, 320, 1024), (4099, 448, 64)])
 def test_x8_gemm_column_tail_tiles(rt3, M, N, K, tune):
     """Column counts that leave the last 256-wide tile partly empty (W rows clamped on load, columns masked on store), with

@@ -393,6 +393,64 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
           x6_store_half(d8 + (size_t)p.M * p.ldc, lv, sb - 10);
         }
       }
+    } else if (STORE == VDN_STX_HEADS && nw < p.N && !p.transposed[nw / (p.heads * 64)] && p.dst8[nw / (p.heads * 64)]) {
+      // Q / K head split with the attention's 8-bit planes (per token 64 B of e5m2(v) | 64 B of e5m2(remainder 2^10)). The wave's
+      // 64-column slab is ONE head; a lane holds its 8-byte groups 16 u + 32 j + 8 h of both planes. Written as they come that
+      // is sixteen 8-byte stores per token pair into 128-byte rows (15 us of the 165 us QKV launch); the two lanes of a token
+      // swap halves instead (v_permlane32_swap: lane h keeps block j = h of each plane) and store 32 contiguous bytes per plane.
+      const int hc = p.heads * 64, split = nw / hc, head = (nw - split * hc) >> 6;
+      _Float16* dst = (_Float16*)p.dst[split];
+      _Float16* dlo = (_Float16*)p.dst_lo[split];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int m = mw + 32 * i + r, mc = m < p.M ? m : p.M - 1;
+        const int bt = mc / p.tokens, tk = mc - bt * p.tokens + p.tok_off;
+        const size_t row = ((size_t)bt * p.heads + head) * p.tpad + tk;
+        unsigned hi8[2][2][2], lo8[2][2][2];   // [j][u][dword]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][8 * u + e] + bias8[j][u][0][e]; v[4 + e] = acc[i][j][8 * u + 4 + e] + bias8[j][u][1][e]; }
+            V8 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              _Float16 h0, h1, l0, l1;
+              split2_rtz(v[e], v[e + 1], h0, h1, l0, l1);
+              hh[e] = h0; hh[e + 1] = h1; ll[e] = l0; ll[e + 1] = l1;
+            }
+            if (m < p.M) {
+              const size_t o = row * 64 + 32 * j + 16 * u + 8 * h;
+              *(V8*)(dst + o) = hh;
+              if (dlo) *(V8*)(dlo + o) = ll;
+            }
+            const float k = VDN_LO8_SCALE;
+            hi8[j][u][0] = pk4_bf8(v[0], v[1], v[2], v[3]);
+            hi8[j][u][1] = pk4_bf8(v[4], v[5], v[6], v[7]);
+            lo8[j][u][0] = pk4_bf8(k * (float)ll[0], k * (float)ll[1], k * (float)ll[2], k * (float)ll[3]);
+            lo8[j][u][1] = pk4_bf8(k * (float)ll[4], k * (float)ll[5], k * (float)ll[6], k * (float)ll[7]);
+          }
+        // after the swap: lanes h = 0 hold (own, partner's) group of block j = 0, lanes h = 1 (partner's, own) of block j = 1
+        u32x4 bh[2], bl[2];   // 32 bytes of each plane: [u0 h0 | u0 h1], [u1 h0 | u1 h1]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const auto sh = __builtin_amdgcn_permlane32_swap(hi8[0][u][w], hi8[1][u][w], false, false);
+            const auto sl = __builtin_amdgcn_permlane32_swap(lo8[0][u][w], lo8[1][u][w], false, false);
+            bh[u][w] = sh[0]; bh[u][2 + w] = sh[1];
+            bl[u][w] = sl[0]; bl[u][2 + w] = sl[1];
+          }
+        if (m < p.M) {
+          uint8_t* d8 = (uint8_t*)p.dst8[split] + row * 128 + 32 * h;
+          *(u32x4*)d8 = bh[0];
+          *(u32x4*)(d8 + 16) = bh[1];
+          *(u32x4*)(d8 + 64) = bl[0];
+          *(u32x4*)(d8 + 80) = bl[1];
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
