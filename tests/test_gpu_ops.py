@@ -1169,6 +1169,44 @@ def test_x8_heads_split_with_attention_planes(rt3, bm, tune):
             assert torch.equal(got[..., 64:], want_lo)
 
 
+@pytest.mark.parametrize("bm", [192, 256])
+def test_x8_heads_split_with_rope(rt3, bm, tune):
+    """The RoPE'd QKV head split of the memory attention on the cross-term kernel (paired epilogue: a pair's real and imaginary
+    columns sit in one lane, the 16 rotated channels are consecutive): Q / K planes, their 8-bit planes and V^T against the same
+    launch on the three-product kernel (generic epilogue, itself fp64-checked in test_x3_heads_rope_and_flash)."""
+    from vdn import pack, _abi
+    from vdn.runtime import ceil_to
+    tune(force_bm=bm)
+    side, B, Hh, K = 37, 3, 2, 128
+    P, C = side * side, Hh * 64
+    tp, M = ceil_to(P, 64), B * P
+    a = rnd(M, K, seed=1240)
+    ws, bs = [rnd(C, K, seed=1241 + i, scale=1 / math.sqrt(K)) for i in range(3)], [rnd(C, seed=1245 + i) for i in range(3)]
+    wp, bp = pack.cat_proj([w.to(DEV) for w in ws], [b.to(DEV) for b in bs], [1, 1, 0], rt3.prec)
+    cs = pack.rope_table(side, side, 64, device=DEV)
+    A = rt3.to_half(a.to(DEV))
+    outs = []
+    for x8 in (False, True):
+        q, k = rt3.hbuf(f"t_hr_q{x8}", (B * Hh, tp, 64), zero=True), rt3.hbuf(f"t_hr_k{x8}", (B * Hh, tp, 64), zero=True)
+        vt = rt3.hbuf(f"t_hr_v{x8}", (B * Hh, 64, tp), zero=True)
+        q8, k8 = rt3.qk8(f"t_hr_q8{x8}", B * Hh, tp), rt3.qk8(f"t_hr_k8{x8}", B * Hh, tp)
+        q8.zero_(); k8.zero_()
+        kw = dict(a8=pack.planes8(A), w8=pack.planes8(wp)) if x8 else {}
+        rt3.gemm(A, wp, M, 3 * C, K, bias=bp, store=_abi.ST_HEADS,
+                 heads=dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], rope=[1, 1, 0], rope_cs=cs, rope_mod=P, heads=Hh,
+                            tokens=P, tpad=tp), **kw)
+        outs.append((q, k, vt, q8, k8))
+    (q3, k3, v3, _, _), (q, k, vt, q8, k8) = outs
+    for got, want in ((q, q3), (k, k3), (vt, v3)):
+        close(got.float(), want.float(), 2e-5)
+    for p8, planes in ((q8, q), (k8, k)):
+        want_hi = planes.float()[:, :P].to(torch.float8_e5m2).view(torch.uint8)
+        got = p8[:, :P]
+        assert (got[..., :64].int() - want_hi.int()).abs().max() <= 1 and (got[..., :64] != want_hi).float().mean() < 2e-3
+        if planes.lo is not None:
+            assert torch.equal(got[..., 64:], (planes.lo.float()[:, :P] * 1024.0).to(torch.float8_e5m2).view(torch.uint8))
+
+
 @pytest.mark.parametrize("M,N,K", [(5500, 192, 128), (4200, 320, 1024), (4099, 448, 64)])
 def test_x8_gemm_column_tail_tiles(rt3, M, N, K, tune):
     """Column counts that leave the last 256-wide tile partly empty (W rows clamped on load, columns masked on store), with

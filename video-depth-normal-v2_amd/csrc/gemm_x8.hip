@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
           x6_store_half(d8 + (size_t)p.M * p.ldc, lv, sb - 10);
         }
       }
-    } else if (STORE == VDN_STX_HEADS && nw < p.N && !p.transposed[nw / (p.heads * 64)] && p.dst8[nw / (p.heads * 64)]) {
+    } else if ((STORE == VDN_STX_HEADS || STORE == VDN_ST_HEADS) && nw < p.N && !p.transposed[nw / (p.heads * 64)] && p.dst8[nw / (p.heads * 64)]) {
       // Q / K head split with the attention's 8-bit planes (per token 64 B of e5m2(v) | 64 B of e5m2(remainder 2^10)). The wave's
       // 64-column slab is ONE head; a lane holds its 8-byte groups 16 u + 32 j + 8 h of both planes. Written as they come that
       // is sixteen 8-byte stores per token pair into 128-byte rows (15 us of the 165 us QKV launch); the two lanes of a token
@@ -401,6 +401,62 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
       const int hc = p.heads * 64, split = nw / hc, head = (nw - split * hc) >> 6;
       _Float16* dst = (_Float16*)p.dst[split];
       _Float16* dlo = (_Float16*)p.dst_lo[split];
+      if (STORE == VDN_ST_HEADS && p.rope[split]) {
+        // RoPE'd split (sam2 apply_rotary_enc; weights packed so that a pair's real part sits 16 columns before its imaginary
+        // part): under the paired mapping both are in this lane — registers 0..7 and 8..15 of block j are pairs 16 j + 8 h + e —
+        // and the 16 rotated values are the CONSECUTIVE output channels 32 j + 16 h + {0..15}: two 16-byte stores per plane,
+        // 16 bytes per 8-bit plane. The (cos, sin) rows of block row i + 1 are fetched before the stores of block row i.
+        f32x4 cs[2][2][4];   // [buffer][j][4 x (cos, sin, cos, sin)]
+        auto fetch = [&](int i, f32x4 (&d)[2][4]) {
+          const int m = mw + 32 * i + r, mc = m < p.M ? m : p.M - 1;
+          const int tl = mc - (mc / p.tokens) * p.tokens;
+          const float* t = p.rope_cs + (size_t)(tl % p.rope_mod) * 64 + 16 * h;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[j][q] = *(const f32x4*)(t + 32 * j + 4 * q);
+        };
+        fetch(0, cs[0]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if (i + 1 < NI) fetch(i + 1, cs[(i + 1) & 1]);
+          const int m = mw + 32 * i + r, mc = m < p.M ? m : p.M - 1;
+          const int bt = mc / p.tokens, tk = mc - bt * p.tokens + p.tok_off;
+          const size_t row = ((size_t)bt * p.heads + head) * p.tpad + tk;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float o[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float re = acc[i][j][e] + bias8[j][0][e >> 2][e & 3], im = acc[i][j][8 + e] + bias8[j][1][e >> 2][e & 3];
+              const float cc = cs[i & 1][j][e >> 1][2 * (e & 1)], ss = cs[i & 1][j][e >> 1][2 * (e & 1) + 1];
+              o[2 * e] = re * cc - im * ss;
+              o[2 * e + 1] = re * ss + im * cc;
+            }
+            V8 hh[2], ll[2];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+              _Float16 h0, h1, l0, l1;
+              split2_rtz(o[e], o[e + 1], h0, h1, l0, l1);
+              hh[e >> 3][e & 7] = h0; hh[e >> 3][(e & 7) + 1] = h1; ll[e >> 3][e & 7] = l0; ll[e >> 3][(e & 7) + 1] = l1;
+            }
+            if (m < p.M) {
+              const size_t oo = row * 64 + 32 * j + 16 * h;
+              *(V8*)(dst + oo) = hh[0];
+              *(V8*)(dst + oo + 8) = hh[1];
+              if (dlo) { *(V8*)(dlo + oo) = ll[0]; *(V8*)(dlo + oo + 8) = ll[1]; }
+              const float k = VDN_LO8_SCALE;
+              uint8_t* d8 = (uint8_t*)p.dst8[split] + row * 128 + 32 * j + 16 * h;
+              *(u32x4*)d8 = u32x4{pk4_bf8(o[0], o[1], o[2], o[3]), pk4_bf8(o[4], o[5], o[6], o[7]), pk4_bf8(o[8], o[9], o[10], o[11]),
+                                  pk4_bf8(o[12], o[13], o[14], o[15])};
+              *(u32x4*)(d8 + 64) = u32x4{pk4_bf8(k * (float)ll[0][0], k * (float)ll[0][1], k * (float)ll[0][2], k * (float)ll[0][3]),
+                                         pk4_bf8(k * (float)ll[0][4], k * (float)ll[0][5], k * (float)ll[0][6], k * (float)ll[0][7]),
+                                         pk4_bf8(k * (float)ll[1][0], k * (float)ll[1][1], k * (float)ll[1][2], k * (float)ll[1][3]),
+                                         pk4_bf8(k * (float)ll[1][4], k * (float)ll[1][5], k * (float)ll[1][6], k * (float)ll[1][7])};
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int m = mw + 32 * i + r, mc = m < p.M ? m : p.M - 1;
@@ -460,7 +516,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const vdn_gemm_desc p) {
           for (int u = 0; u < 2; ++u) {
             const f32x4 a0 = {acc[i][j][8 * u], acc[i][j][8 * u + 1], acc[i][j][8 * u + 2], acc[i][j][8 * u + 3]};
             const f32x4 a1 = {acc[i][j][8 * u + 4], acc[i][j][8 * u + 5], acc[i][j][8 * u + 6], acc[i][j][8 * u + 7]};
-            emit8<VDN_F16, STORE>(p, mw + 32 * i + r, nw + 32 * j + 16 * u + 8 * h, a0, a1, bias8[j][u][0], bias8[j][u][1]);
+            emit8<VDN_F16, STORE == VDN_ST_HEADS ? VDN_STX_HEADS : STORE>(p, mw + 32 * i + r, nw + 32 * j + 16 * u + 8 * h, a0, a1, bias8[j][u][0],
+                                                                              bias8[j][u][1]);
           }
     }
   } else if constexpr (STORE == VDN_STX_RES) {  // (acc + bias) * gamma + f32 residual -> f32 rows (in place)
@@ -552,7 +609,15 @@ static int x8_launch(const vdn_gemm_desc& d, hipStream_t s) {
     case VDN_STX_HEADS: VDN_X8(VDN_STX_HEADS, true); break;
     case VDN_STX_RES: VDN_X8(VDN_STX_RES, false); break;
     case VDN_ST_GEGLU: VDN_X8(VDN_ST_GEGLU, false); break;
-    case VDN_ST_HEADS: VDN_X8(VDN_ST_HEADS, false); break;
+    case VDN_ST_HEADS: {
+      // RoPE'd head splits: the paired epilogue when every split is a transposed one (V^T) or a Q / K split with its 8-bit planes
+      bool pair = a8 && d.nsplit >= 1 && d.rope_cs && !((uintptr_t)d.rope_cs & 15);
+      for (int i = 0; i < d.nsplit && pair; ++i)
+        pair = d.dst[i] && (d.transposed[i] ? !d.rope[i] : d.dst8[i] != nullptr);
+      if (pair) VDN_X8(VDN_ST_HEADS, true);
+      else VDN_X8(VDN_ST_HEADS, false);
+      break;
+    }
     default: VDN_X8(VDN_ST_PLAIN, false); break;
   }
 #undef VDN_X8
