@@ -135,19 +135,33 @@ namespace {
 // Operand planes of the 8-bit cross-term GEMM from fp16 split planes (include/vdn.h: vdn_pack_x8): the hi plane again
 // K-tile-major and the two planes of 6-bit rows (hi, remainder; common.hpp 'x6 rows'), K-tile-major or row-major. One thread
 // per row, 64-wide K slab and half: 32 values gathered in the stream order of the activation's producer.
+template <int ORDER>   // compile-time stream order: the gather below is register renaming, the 64 values come in as 16-byte loads
 __global__ __launch_bounds__(256) void pack_x8_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int rows,
-                                                      int ld, _Float16* __restrict__ hi_kt, uint8_t* __restrict__ p8, int kt, int order) {
+                                                      int ld, _Float16* __restrict__ hi_kt, uint8_t* __restrict__ p8, int kt) {
   const size_t total = (size_t)rows * (ld >> 5);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / (ld >> 5)), hb = (int)(i - (size_t)r * (ld >> 5)), slab = hb >> 1, h = hb & 1;
     const _Float16* hr = hi + (size_t)r * ld + slab * 64;
     const _Float16* lr = lo + (size_t)r * ld + slab * 64;
+    // a half's 32 values are runs of 32, 8 or 4 consecutive columns (common.hpp x6_col): vector loads at addresses that depend
+    // on h, register positions fixed at compile time
     f16x32 hv, lv;
+    if constexpr (ORDER == 2) {
 #pragma unroll
-    for (int p = 0; p < 32; ++p) {
-      const int c = x6_col(order, h, p);
-      hv[p] = hr[c];
-      lv[p] = lr[c];
+      for (int q = 0; q < 8; ++q) {   // position 4 q .. 4 q + 3 = columns 32 (q >> 2) + 8 (q & 3) + 4 h + {0..3}
+        const int c = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+        const f16x4 a = *(const f16x4*)(hr + c), b = *(const f16x4*)(lr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hv[4 * q + e] = a[e]; lv[4 * q + e] = b[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // position 8 q .. 8 q + 7: order 0 columns 32 h + 8 q, order 1 columns 32 (q >> 1) + 16 (q & 1) + 8 h
+        const int c = ORDER == 0 ? 32 * h + 8 * q : 32 * (q >> 1) + 16 * (q & 1) + 8 * h;
+        const f16x8 a = *(const f16x8*)(hr + c), b = *(const f16x8*)(lr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hv[8 * q + e] = a[e]; lv[8 * q + e] = b[e]; }
+      }
     }
     if (hi_kt) {  // natural column order: K tile 2 slab + h of this row
       _Float16* d = hi_kt + ((size_t)(2 * slab + h) * rows + r) * 32;
@@ -170,8 +184,9 @@ extern "C" int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, voi
   if (hi_kt && !kt) return VDN_EINVAL;
   const size_t work = (size_t)rows * (ld >> 5);
   const dim3 g((unsigned)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192));
-  hipLaunchKernelGGL(pack_x8_kernel, g, dim3(256), 0, (hipStream_t)stream, (const _Float16*)hi, (const _Float16*)lo, rows, ld,
-                     (_Float16*)hi_kt, (uint8_t*)planes8, kt, order);
+  const auto kern = order == 0 ? pack_x8_kernel<0> : order == 1 ? pack_x8_kernel<1> : pack_x8_kernel<2>;
+  hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, (const _Float16*)hi, (const _Float16*)lo, rows, ld,
+                     (_Float16*)hi_kt, (uint8_t*)planes8, kt);
   VDN_CHECK_LAUNCH();
   return VDN_OK;
 }

@@ -539,7 +539,8 @@ class MemoryEngine:
         if self.x8:
             for L in self.layers:
                 L["x8"] = {k: pack.X8(L[k], o) for k, o in (("wqkv", pack.ORDER_NATURAL), ("wso", pack.ORDER_ATTN), ("wq", pack.ORDER_NATURAL),
-                                                            ("wco", pack.ORDER_ATTN), ("w1", pack.ORDER_NATURAL), ("w2", pack.ORDER_GEMM))}
+                                                            ("wco", pack.ORDER_ATTN), ("w1", pack.ORDER_NATURAL), ("w2", pack.ORDER_GEMM),
+                                                            ("wkv", pack.ORDER_NATURAL))}
             for cx in self.cx:
                 cx["x8"] = {"w1": pack.X8(cx["w1"], pack.ORDER_NATURAL), "w2": pack.X8(cx["w2"], pack.ORDER_GEMM)}
         # Bank state shared by every lane copy of this engine (DepthAnythingV2._stream_lanes): ONE ring for the whole
@@ -712,8 +713,17 @@ class MemoryEngine:
         ks, vs, k8s, tp = self._bank(B, P)
         slot = self.state["count"] % self.max_len  # commit() advances the count once every lane has pushed
         cs = self._rope_for(int(math.sqrt(P)))
+        if use8 and feat.lo is not None:
+            # the four key / value projections of the pushed frame on the cross-term kernel: one pass turns the memory feature's
+            # split planes into its A operand (K-tile-major hi plane + 6-bit rows) for all of them
+            feat_k, feat8 = HL(rt.buf("mem_feat_kt", (M, C), rt.half)), rt.buf("mem_feat8", (2, M, C), torch.uint8)
+            rt.pack_x8(feat, feat_k.hi, feat8)
         for l, L in enumerate(self.layers):
-            rt.gemm(feat, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS,
-                    heads=dict(dst=[rt.qk_dst(ks[l], k8s[l]), rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P,
-                               heads=Hh, tokens=P, tok_off=slot * P, tpad=tp))
+            hd = dict(dst=[rt.qk_dst(ks[l], k8s[l]), rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P,
+                      heads=Hh, tokens=P, tok_off=slot * P, tpad=tp)
+            if use8 and feat.lo is not None:
+                xw = L["x8"]["wkv"]
+                rt.gemm(feat_k, HL(xw.hi), M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS, heads=hd, a8=feat8, w8=xw.p8, a_kt=True, w_kt=True)
+            else:
+                rt.gemm(feat, L["wkv"], M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS, heads=hd)
         return feat

@@ -360,5 +360,11 @@ class Runtime:
         yh, yl = _hl(y)
         self._launch(abi.lib.vdn_addtab_cast, self.dt, x.data_ptr(), self._p(tab), tab_div, tab_mod, yh.data_ptr(), yl, rows, Cn)
 
+    def pack_x8(self, t: HL, hi_kt: torch.Tensor, planes8: torch.Tensor, order: int = 0):
+        """Split planes [rows, ld] -> the K-tile-major hi plane and the two planes of 6-bit rows of the cross-term GEMM's A operand
+        (include/vdn.h vdn_pack_x8), for activations whose producer writes plain split planes."""
+        rows, ld = t.hi.shape
+        self._launch(abi.lib.vdn_pack_x8, t.hi.data_ptr(), t.lo.data_ptr(), rows, ld, hi_kt.data_ptr(), planes8.data_ptr(), 1, order)
+
     def cast(self, x, y):
         self._launch(abi.lib.vdn_cast, x.data_ptr(), _TDT[x.dtype], y.data_ptr(), _TDT[y.dtype], x.numel())
