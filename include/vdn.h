@@ -381,6 +381,10 @@ int vdn_pack_bias(int kind, const float* b, int d0, int d1, int d2, float* out, 
  *   2  col = 32 (p >> 4) + 8 ((p >> 2) & 3) + 4 h + (p & 3)      A from vdn_flash_attn out8                              */
 int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, int order,
                 vdn_stream stream);
+/* The same from an fp32 activation x [rows, ld] (ld % 64 == 0) whose producer writes no half planes (a residual stream that
+ * feeds a GEMM without a LayerNorm in between: the memory feature of memory_encoder.py:173-181 before the key / value
+ * projections of memory_attention.py): hi_kt = fp16 hi plane toward zero, K-tile-major; planes8 = u8 [2][ld/64][rows][64], order 0. */
+int vdn_pack_x8_f32(const float* x, int rows, int ld, void* hi_kt, void* planes8, vdn_stream stream);
 
 /* Workspace sizing (the library allocates nothing): bytes of split-K scratch worth passing as vdn_gemm_desc.splitk_ws
  * for this descriptor (0 = the shape never splits), and the partial-sum buffer of vdn_groupnorm.

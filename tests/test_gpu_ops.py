@@ -1274,6 +1274,25 @@ def test_x8_gemm_outlier_channels_zero_rows_and_large_values(rt3):
     _check_x6(pack.planes8(A), A, M, K, pack.ORDER_NATURAL)
 
 
+@pytest.mark.parametrize("rows,C", [(77, 384), (4100, 1024)])
+def test_pack_x8_from_fp32(rt3, rows, C):
+    """vdn_pack_x8_f32: an fp32 activation straight to the cross-term GEMM's A operand: the hi plane is the value toward zero,
+    and the 6-bit rows are those vdn_pack_x8 makes of that split."""
+    from vdn import pack
+    from vdn.runtime import HL
+    x = (rnd(rows, C, seed=1250) * 3.0).to(DEV)
+    x[5] = 0.0
+    x[:, 7] *= 120.0
+    hi_kt = torch.zeros(rows, C, dtype=torch.float16, device=DEV)
+    p8 = torch.zeros(2, rows, C, dtype=torch.uint8, device=DEV)
+    rt3.pack_x8_f32(x, hi_kt, p8)
+    hi = _unkt16(hi_kt, rows, C)
+    assert (hi.float().abs() <= x.abs()).all() and ((x - hi.float()).abs() <= x.abs() * 2.0 ** -10 + 2.0 ** -24).all()   # toward zero, within an ulp (fp16 subnormals: 2^-24)
+    split = HL(hi.contiguous(), (x - hi.float()).half())
+    _same_rows(p8, pack.planes8(split, pack.ORDER_NATURAL, kt=True))
+    _check_x6(p8, split, rows, C, pack.ORDER_NATURAL, kt=True)
+
+
 @pytest.mark.parametrize("rows,C", [(77, 384), (1370, 1024), (300, 64)])
 def test_layernorm_8bit_planes_and_k_tile_major(rt3, rows, C):
     """vdn_layernorm(out8, kt): the hi plane + the planes of 6-bit rows of the cross-term GEMM's A operand, row-major and

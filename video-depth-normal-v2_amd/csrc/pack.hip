@@ -175,7 +175,50 @@ __global__ __launch_bounds__(256) void pack_x8_kernel(const _Float16* __restrict
   }
 }
 
+// the same from an fp32 activation [rows, ld] (natural order, K-tile-major): split toward zero, hi plane + the two planes of 6-bit rows
+__global__ __launch_bounds__(256) void pack_x8_f32_kernel(const float* __restrict__ x, int rows, int ld, _Float16* __restrict__ hi_kt,
+                                                          uint8_t* __restrict__ p8) {
+  const size_t total = (size_t)rows * (ld >> 5);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / (ld >> 5)), hb = (int)(i - (size_t)r * (ld >> 5));
+    const float* xr = x + (size_t)r * ld + hb * 32;
+    f16x32 hv, lv;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 a = *(const f32x4*)(xr + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        _Float16 h0, h1, l0, l1;
+        split2_rtz(a[e], a[e + 1], h0, h1, l0, l1);
+        hv[4 * q + e] = h0; hv[4 * q + e + 1] = h1; lv[4 * q + e] = l0; lv[4 * q + e + 1] = l1;
+      }
+    }
+    _Float16* d = hi_kt + ((size_t)hb * rows + r) * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = hv[8 * q + e];
+      *(f16x8*)(d + 8 * q) = o;
+    }
+    const int sb = x6_scale_byte(hv);
+    uint8_t* d8 = p8 + ((size_t)(hb >> 1) * rows + r) * 64 + 32 * (hb & 1);
+    x6_store_half(d8, hv, sb);
+    x6_store_half(d8 + (size_t)rows * ld, lv, sb - 10);
+  }
+}
+
 }  // namespace
+
+extern "C" int vdn_pack_x8_f32(const float* x, int rows, int ld, void* hi_kt, void* planes8, vdn_stream stream) {
+  if (!x || !hi_kt || !planes8 || rows <= 0 || ld <= 0 || (ld & 63)) return VDN_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)hi_kt | (uintptr_t)planes8) & 15) return VDN_EALIGN;
+  const size_t work = (size_t)rows * (ld >> 5);
+  const dim3 g((unsigned)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192));
+  hipLaunchKernelGGL(pack_x8_f32_kernel, g, dim3(256), 0, (hipStream_t)stream, x, rows, ld, (_Float16*)hi_kt, (uint8_t*)planes8);
+  VDN_CHECK_LAUNCH();
+  return VDN_OK;
+}
 
 extern "C" int vdn_pack_x8(const void* hi, const void* lo, int rows, int ld, void* hi_kt, void* planes8, int kt, int order,
                            vdn_stream stream) {

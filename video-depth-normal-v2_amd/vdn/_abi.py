@@ -92,6 +92,7 @@ EXPORTS = {
     "vdn_pack_weight": (C.c_int, [C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "vdn_pack_bias": (C.c_int, [C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, vp]),
     "vdn_pack_x8": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "vdn_pack_x8_f32": (C.c_int, [fp, C.c_int, C.c_int, vp, vp, vp]),
     "vdn_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "vdn_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vdn_mask_down1": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]),

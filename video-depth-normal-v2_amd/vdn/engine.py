@@ -689,14 +689,14 @@ class MemoryEngine:
         x = rt.fbuf("me_x", (M, C))
         rt.gemm(mem_out, self.wpix, M, C, C, bias=self.bpix, rowadd=m2, out=x)
         d = rt.fbuf("me_dw", (M, C))
-        feat = rt.hbuf("mem_feat", (M, C))
         use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096"))
         if use8:
             from .runtime import HL
             n_k, n8 = HL(rt.buf("me_n_kt", (M, C), rt.half)), rt.buf("me_n8", (2, M, C), torch.uint8)
             h4_k, h48 = HL(rt.buf("me_h4_kt", (M, 4 * C), rt.half)), rt.buf("me_h48", (2, M, 4 * C), torch.uint8)
+            feat = None   # the memory feature stays in the fp32 stream x and goes straight to the projections' operand planes
         else:
-            n, h4 = rt.hbuf("me_n", (M, C)), rt.hbuf("me_h4", (M, 4 * C))
+            n, h4, feat = rt.hbuf("me_n", (M, C)), rt.hbuf("me_h4", (M, 4 * C)), rt.hbuf("mem_feat", (M, C))
         for j, cx in enumerate(self.cx):
             rt.dwconv7(x, d, B, ph, pw, C, cx["wdw"], cx["bdw"])
             if use8:
@@ -704,8 +704,7 @@ class MemoryEngine:
                 rt.layernorm(d, M, C, cx["nw"], cx["nb"], 1e-6, out_h=n_k, out8=n8, kt=True)
                 rt.gemm(n_k, HL(x8["w1"].hi), M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4_k, out8=h48, out_kt=True, a8=n8, w8=x8["w1"].p8,
                         a_kt=True, w_kt=True)
-                rt.gemm(h4_k, HL(x8["w2"].hi), M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=(x if j == 0 else feat), a8=h48,
-                        w8=x8["w2"].p8, a_kt=True, w_kt=True)
+                rt.gemm(h4_k, HL(x8["w2"].hi), M, C, 4 * C, bias=cx["b2"], gamma=cx["g"], res1=x, out=x, a8=h48, w8=x8["w2"].p8, a_kt=True, w_kt=True)
                 continue
             rt.layernorm(d, M, C, cx["nw"], cx["nb"], 1e-6, out_h=n)
             rt.gemm(n, cx["w1"], M, 4 * C, C, bias=cx["b1"], act=GELU, out=h4)
@@ -713,15 +712,15 @@ class MemoryEngine:
         ks, vs, k8s, tp = self._bank(B, P)
         slot = self.state["count"] % self.max_len  # commit() advances the count once every lane has pushed
         cs = self._rope_for(int(math.sqrt(P)))
-        if use8 and feat.lo is not None:
-            # the four key / value projections of the pushed frame on the cross-term kernel: one pass turns the memory feature's
-            # split planes into its A operand (K-tile-major hi plane + 6-bit rows) for all of them
+        if use8:
+            # the four key / value projections of the pushed frame on the cross-term kernel: one pass turns the fp32 memory feature
+            # into their A operand (K-tile-major hi plane + 6-bit rows); its two ConvNeXt blocks both ran in place on x
             feat_k, feat8 = HL(rt.buf("mem_feat_kt", (M, C), rt.half)), rt.buf("mem_feat8", (2, M, C), torch.uint8)
-            rt.pack_x8(feat, feat_k.hi, feat8)
+            rt.pack_x8_f32(x, feat_k.hi, feat8)
         for l, L in enumerate(self.layers):
             hd = dict(dst=[rt.qk_dst(ks[l], k8s[l]), rt.v_dst(vs[l])], dst8=[k8s[l], None], transposed=[0, 1], rope=[1, 0], rope_cs=cs, rope_mod=P,
                       heads=Hh, tokens=P, tok_off=slot * P, tpad=tp)
-            if use8 and feat.lo is not None:
+            if use8:
                 xw = L["x8"]["wkv"]
                 rt.gemm(feat_k, HL(xw.hi), M, 2 * C, C, bias=L["bkv"], store=abi.ST_HEADS, heads=hd, a8=feat8, w8=xw.p8, a_kt=True, w_kt=True)
             else:

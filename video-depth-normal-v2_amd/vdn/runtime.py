@@ -366,5 +366,10 @@ class Runtime:
         rows, ld = t.hi.shape
         self._launch(abi.lib.vdn_pack_x8, t.hi.data_ptr(), t.lo.data_ptr(), rows, ld, hi_kt.data_ptr(), planes8.data_ptr(), 1, order)
 
+    def pack_x8_f32(self, x: torch.Tensor, hi_kt: torch.Tensor, planes8: torch.Tensor):
+        """fp32 [rows, ld] -> the cross-term GEMM's A operand (include/vdn.h vdn_pack_x8_f32)."""
+        rows, ld = x.shape
+        self._launch(abi.lib.vdn_pack_x8_f32, x.data_ptr(), rows, ld, hi_kt.data_ptr(), planes8.data_ptr())
+
     def cast(self, x, y):
         self._launch(abi.lib.vdn_cast, x.data_ptr(), _TDT[x.dtype], y.data_ptr(), _TDT[y.dtype], x.numel())
