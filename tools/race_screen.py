@@ -66,6 +66,35 @@ for bm in (256, 192):
             diff += int(not (torch.equal(oh.hi, h0) and torch.equal(o8, p0) and torch.equal(res, r0)))
         bad += diff
         print(f"gemm_x8 BM={bm} M={M} N={N} K={K} (GELU planes + residual): {diff} of {reps // 2} runs differ", flush=True)
+    # head-split epilogues of the cross-term kernel: lane-half swap of the 8-bit planes, and the RoPE'd flavour
+    side, Bh, Hh, K = 37, 4, 4, 256
+    P, C = side * side, Hh * 64
+    tp, M = ceil_to(P, 64), Bh * P
+    a = rt.to_half(torch.randn(M, K, device="cuda"))
+    ws, bs = [torch.randn(C, K, device="cuda") / math.sqrt(K) for _ in range(3)], [torch.randn(C, device="cuda") for _ in range(3)]
+    cs = pack.rope_table(side, side, 64, device="cuda")
+    a8 = pack.planes8(a)
+    for rope in (0, 1):
+        wp, bp = pack.cat_proj(ws, bs, [rope, rope, 0], rt.prec)
+        w8 = pack.planes8(wp)
+        q, k = rt.hbuf(f"rs_q{rope}", (Bh * Hh, tp, 64), zero=True), rt.hbuf(f"rs_k{rope}", (Bh * Hh, tp, 64), zero=True)
+        vt = rt.hbuf(f"rs_vt{rope}", (Bh * Hh, 64, tp), zero=True)
+        q8, k8 = rt.qk8(f"rs_q8{rope}", Bh * Hh, tp), rt.qk8(f"rs_k8{rope}", Bh * Hh, tp)
+        hd = dict(dst=[q, k, vt], dst8=[q8, k8, None], transposed=[0, 0, 1], heads=Hh, tokens=P, tpad=tp)
+        if rope:
+            hd.update(rope=[1, 1, 0], rope_cs=cs, rope_mod=P)
+
+        def run_h():
+            rt.gemm(a, wp, M, 3 * C, K, bias=bp, store=_abi.ST_HEADS, heads=hd, a8=a8, w8=w8)
+
+        run_h()
+        ref = [t.clone() for t in (q.hi, k.hi, vt.hi, q8, k8)]
+        diff = 0
+        for _ in range(reps // 2):
+            run_h()
+            diff += int(not all(torch.equal(x, y) for x, y in zip((q.hi, k.hi, vt.hi, q8, k8), ref)))
+        bad += diff
+        print(f"gemm_x8 BM={bm} head split{' + RoPE' if rope else ''} M={M} N={3 * C} K={K}: {diff} of {reps // 2} runs differ", flush=True)
 _abi.set_tuning(force_bm=0)
 for (B, H, nq, nk) in ((8, 16, 1370, 1370), (4, 16, 1369, 8214), (2, 6, 150, 200), (1, 16, 361, 1369)):
     qp, kp = ceil_to(nq, 64), ceil_to(nk, 64)
