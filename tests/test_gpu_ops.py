@@ -1170,6 +1170,40 @@ def test_x8_heads_split_with_attention_planes(rt3, bm, tune):
 
 
 @pytest.mark.parametrize("bm", [192, 256])
+def test_x8_gated_and_plain_half_plane_stores(rt3, bm, tune):
+    """The temporal module's LayerNorm-fed linears on the cross-term kernel: the gated (GEGLU) store and the plain split-plane
+    store without bias, A from vdn_layernorm's K-tile-major planes with the position table added — against the three-product
+    kernel on the same LayerNorm's split planes, and the gated one against fp64."""
+    from vdn import pack, _abi
+    from vdn.runtime import HL
+    tune(force_bm=bm)
+    M, c, T, D = 4160, 256, 4, 1040
+    x = rnd(M, c, seed=1260).to(DEV)
+    w, b = rnd(c, seed=1261).to(DEV), rnd(c, seed=1262).to(DEV)
+    tab = rnd(T, c, seed=1263).to(DEV)
+    n = rt3.hbuf("t_gp_n", (M, c))
+    rt3.layernorm(x, M, c, w, b, 1e-5, out_h=n, addtab=tab, tab_div=D, tab_mod=T)
+    n_k, n8 = HL(torch.zeros(M, c, dtype=torch.float16, device=DEV)), torch.zeros(2, M, c, dtype=torch.uint8, device=DEV)
+    rt3.layernorm(x, M, c, w, b, 1e-5, out_h=n_k, out8=n8, kt=True, addtab=tab, tab_div=D, tab_mod=T)
+    kt = dict(a8=n8, a_kt=True, w_kt=True)
+    wq = pack.linear(rnd(3 * c, c, seed=1264, scale=1 / math.sqrt(c)).to(DEV), rt3.prec)
+    q3, q8 = rt3.hbuf("t_gp_q3", (M, 3 * c)), rt3.hbuf("t_gp_q8", (M, 3 * c))
+    rt3.gemm(n, wq, M, 3 * c, c, out=q3)
+    Xq = pack.X8(wq)
+    rt3.gemm(n_k, HL(Xq.hi), M, 3 * c, c, out=q8, w8=Xq.p8, **kt)
+    close(q8.float(), q3.float(), 5e-5)   # K = 256: the 2^-14 cross terms average over fewer products than at K = 1024
+    wgf, bgf = rnd(8 * c, c, seed=1265, scale=1 / math.sqrt(c)), rnd(8 * c, seed=1266)
+    wg, bg = pack.geglu(wgf.to(DEV), bgf.to(DEV), rt3.prec)
+    g3, g8 = rt3.hbuf("t_gp_g3", (M, 4 * c)), rt3.hbuf("t_gp_g8", (M, 4 * c))
+    rt3.gemm(n, wg, M, 8 * c, c, bias=bg, store=_abi.ST_GEGLU, out=g3)
+    Xg = pack.X8(wg)
+    rt3.gemm(n_k, HL(Xg.hi), M, 8 * c, c, bias=bg, store=_abi.ST_GEGLU, out=g8, w8=Xg.p8, **kt)
+    close(g8.float(), g3.float(), 6e-5)
+    y = n.float().double().cpu() @ wgf.double().t() + bgf.double()
+    close(g8.float(), (y[:, : 4 * c] * F.gelu(y[:, 4 * c:])).float(), 6e-5)
+
+
+@pytest.mark.parametrize("bm", [192, 256])
 def test_x8_heads_split_with_rope(rt3, bm, tune):
     """The RoPE'd QKV head split of the memory attention on the cross-term kernel (paired epilogue: a pair's real and imaginary
     columns sit in one lane, the 16 rotated channels are consecutive): Q / K planes, their 8-bit planes and V^T against the same

@@ -246,6 +246,14 @@ class TemporalEngine:
                 wo=pack.linear(a.to_out[0].weight, h), bo=pack.f32(a.to_out[0].bias)))
         self.fnw, self.fnb = pack.f32(blk.ff_norm.weight), pack.f32(blk.ff_norm.bias)
         self.wg, self.bg = pack.geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, h)
+        # the LayerNorm-fed linears (q|k|v of both attention blocks, the gated feed-forward's first layer: 14 of the module's
+        # 22 c^2 products per row) on the cross-term kernel when a window brings >= 4096 rows; the others take their input from
+        # kernels that write no 6-bit rows (GroupNorm, the attention over frames, the gated epilogue)
+        self.x8 = rt.split and rt.half == torch.float16 and c % 64 == 0 and os.environ.get("VDN_X8", "1") != "0"
+        if self.x8:
+            for at in self.att:
+                at["x8"] = pack.X8(at["wqkv"], pack.ORDER_NATURAL)
+            self.xg = pack.X8(self.wg, pack.ORDER_NATURAL)
         self.wf2, self.bf2 = pack.linear(blk.ff.net[2].weight, h), pack.f32(blk.ff.net[2].bias)
         self.w_out, self.b_out = pack.linear(tt.proj_out.weight, h), pack.f32(tt.proj_out.bias)
 
@@ -263,17 +271,31 @@ class TemporalEngine:
         assert T <= self.att[0]["max_len"], "clip longer than temporal_max_len (motion_module.py:200-213)"
         hs = rt.fbuf("tm_h", (M, c))
         rt.gemm(g, self.w_in, M, c, c, bias=self.b_in, out=hs)
-        n = rt.hbuf("tm_n", (M, c))
+        use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096"))
+        if use8:
+            from .runtime import HL
+            n_k, n8 = HL(rt.buf("tm_n_kt", (M, c), rt.half)), rt.buf("tm_n8", (2, M, c), torch.uint8)
+            kt = dict(a8=n8, a_kt=True, w_kt=True)
+        else:
+            n = rt.hbuf("tm_n", (M, c))
         qkv = rt.hbuf("tm_qkv", (M, 3 * c))
         a = rt.hbuf("tm_a", (M, c))
         for at in self.att:
-            rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n, addtab=at["pe"], tab_div=D, tab_mod=T)
-            rt.gemm(n, at["wqkv"], M, 3 * c, c, out=qkv)
+            if use8:
+                rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n_k, out8=n8, kt=True, addtab=at["pe"], tab_div=D, tab_mod=T)
+                rt.gemm(n_k, HL(at["x8"].hi), M, 3 * c, c, out=qkv, w8=at["x8"].p8, **kt)
+            else:
+                rt.layernorm(hs, M, c, at["nw"], at["nb"], 1e-5, out_h=n, addtab=at["pe"], tab_div=D, tab_mod=T)
+                rt.gemm(n, at["wqkv"], M, 3 * c, c, out=qkv)
             rt.temporal_attn(qkv, a, B, T, D, c, 8, (c // 8) ** -0.5, rope_cs=at["rope_cs"])
             rt.gemm(a, at["wo"], M, c, c, bias=at["bo"], res1=hs, out=hs)
-        rt.layernorm(hs, M, c, self.fnw, self.fnb, 1e-5, out_h=n)
         gg = rt.hbuf("tm_gg", (M, 4 * c))
-        rt.gemm(n, self.wg, M, 8 * c, c, bias=self.bg, store=abi.ST_GEGLU, out=gg)
+        if use8:
+            rt.layernorm(hs, M, c, self.fnw, self.fnb, 1e-5, out_h=n_k, out8=n8, kt=True)
+            rt.gemm(n_k, HL(self.xg.hi), M, 8 * c, c, bias=self.bg, store=abi.ST_GEGLU, out=gg, w8=self.xg.p8, **kt)
+        else:
+            rt.layernorm(hs, M, c, self.fnw, self.fnb, 1e-5, out_h=n)
+            rt.gemm(n, self.wg, M, 8 * c, c, bias=self.bg, store=abi.ST_GEGLU, out=gg)
         hh = rt.hbuf("tm_hh", (M, c))
         rt.gemm(gg, self.wf2, M, c, 4 * c, bias=self.bf2, res1=hs, out=hh)
         return hh
