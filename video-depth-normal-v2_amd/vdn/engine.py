@@ -271,7 +271,8 @@ class TemporalEngine:
         assert T <= self.att[0]["max_len"], "clip longer than temporal_max_len (motion_module.py:200-213)"
         hs = rt.fbuf("tm_h", (M, c))
         rt.gemm(g, self.w_in, M, c, c, bias=self.b_in, out=hs)
-        use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096"))
+        # (the kernel takes launches of >= 2^20 outputs: narrow modules of small windows stay on the three-product kernels)
+        use8 = self.x8 and M >= int(os.environ.get("VDN_X8_MIN_ROWS", "4096")) and M * 3 * c >= (1 << 20)
         if use8:
             from .runtime import HL
             n_k, n8 = HL(rt.buf("tm_n_kt", (M, c), rt.half)), rt.buf("tm_n8", (2, M, c), torch.uint8)
